@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- docs/sec of the Cruller pretrain step on N MI355X (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps K --warmup W
+
+A "step" = one TaskCrullerPretrain.train_step(sample) on synthetic inputs already converted to
+device tensors' source (pinned host batch of B docs): H2D, forward, CE, backward (+bucketed
+all-reduce), unscale/clip/AdamW/zero_grad, LR update.  Workload at N=1 = BASELINE.json configs[2]:
+cruller_large (ViT-L/14 CLIP + BART-large 10L) bf16, 1280x960x3, 1024 tokens, batch 8 per GPU.
+Prints ONE JSON line (rank 0) with the driver's contract + `roofline` + `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md "Chip-level parameters")
+METRIC = 'docs/sec (whole node) cruller_large bf16 1280x960, 1/2/4/8 MI355X'
+
+
+def flops_per_doc(task):
+    """algorithmic forward FLOPs per document (SURVEY §8d convention: 2mnk per GEMM, attention 4*Nq*Nk*D per
+    layer, causal self-attention at 1/2, elementwise ignored); train = 3x."""
+    m = task.model
+    V = m.vocab_size
+    T = m.max_length - 1
+    da = m.dec_arch
+    D, F, L = da['d_model'], da['ffn'], m.n_layers
+    if m.enc_kind == 'vit':
+        a = m.enc_arch
+        P, De, dep = a['patch'], a['dim'], a['depth']
+        gh, gw = m.img_size[0] // P, m.img_size[1] // P
+        N = gh * gw + 1
+        enc = dep * (24 * N * De * De + 4 * N * N * De) + 2 * (N - 1) * (P * P * m.in_chans) * De
+        S = N
+    else:
+        from pixparse_amd.layers.engines import SwinEngine
+        a = m.enc_arch
+        enc = 0
+        geo = SwinEngine.stage_geometry(a, m.img_size)
+        for si, (Hf, Wf, C, heads, w, depth) in enumerate(geo):
+            n = Hf * Wf
+            enc += depth * (24 * n * C * C + 4 * n * (w * w) * C)
+            if si > 0:
+                enc += 2 * n * (2 * C) * C
+        enc += 2 * geo[0][0] * geo[0][1] * (a['patch'] ** 2 * m.in_chans) * a['embed_dim']
+        S = geo[-1][0] * geo[-1][1]
+    dec = L * (8 * T * D * D + 4 * T * D * D + 4 * S * D * D + 4 * T * D * F + 2 * T * T * D + 4 * T * S * D) + 2 * T * D * V
+    return float(enc + dec), S
+
+
+def time_kernel(fn, iters=3):
+    """average duration (ms) of `fn` (one or more launches on the current stream) by HIP events"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def dominant_kernel_roofline(task, B):
+    """time the three heaviest kernels of the step standalone on the live activation buffers of encoder block 0 and
+    report the one with the largest share of the step (launch count x duration)."""
+    from pixparse_amd import ops
+    m = task.model
+    enc, dec, bufs = m._engines
+    if m.enc_kind != 'vit':
+        return None
+    T = bufs.t
+    D, H, N, F = enc.D, enc.heads, enc.N, enc.F
+    depth = enc.a['depth']
+    M = B * N
+    scale = (D // H) ** -0.5
+    qkv, o, lse = T['vit.b0.qkv'], T['vit.b0.o'], T['vit.b0.lse']
+    q3 = qkv.view(B, N, 3 * D)
+    do = torch.randn(B, N, D, device=qkv.device).to(torch.bfloat16)
+    dqkv = torch.empty_like(qkv).view(B, N, 3 * D)
+    delta = torch.empty(B, H, N, device=qkv.device)
+    o2 = torch.empty_like(o)
+    lse2 = torch.empty_like(lse)
+    h2, act, pre = T['vit.b0.ln2.y16'], torch.empty_like(T['vit.b0.act']), torch.empty_like(T['vit.b0.pre'])
+    w1, b1 = enc.W('blocks.0.mlp.fc1.weight'), enc.P('blocks.0.mlp.fc1.bias')
+    cand = {}
+    t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False))
+    cand['attn_fwd_kernel<false> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
+    t = time_kernel(lambda: ops.attn_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do, lse, delta,
+                                         dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False))
+    cand['attn_bwd (delta + dkdv + dq kernels, ViT MHSA bwd)'] = (t, 8.0 * N * N * D * B, depth)   # algorithmic bwd = 2x fwd
+    t = time_kernel(lambda: ops.linear_fwd(h2, w1, b1, act, ops.EPI_BF16_GELU, aux=pre))
+    # per block: qkv (3D) + proj (D) + fc1 (F) + fc2 (F) columns forward, twice that again in backward
+    gemm_equiv = 3.0 * (3 * D + D + 2 * F) / F
+    cand['gemm_kernel<NT,GELU,64> (fc1 49512x4096x1024)'] = (t, 2.0 * M * F * D, depth * gemm_equiv)
+    best = max(cand.items(), key=lambda kv: kv[1][0] * kv[1][2])
+    name, (ms, flops, cnt) = best
+    achieved = flops / (ms * 1e-3) / 1e12
+    table = {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1), 'launch_equiv_per_step': round(v[2], 1)} for k, v in cand.items()}
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'ms_per_launch': round(ms, 3), 'candidates': table}
+
+
+def cpu_baseline(model_name, flops_train_per_doc):
+    """oracle (CPU restatement, bf16 policy, torch SDPA for attention) timed on the host cores on a bounded sample:
+    the same architecture at full sequence lengths, batch 1, truncated to 2 encoder blocks + 1 decoder layer,
+    one forward+backward; docs/s extrapolated by algorithmic FLOPs."""
+    from oracle import ref_cpu as R
+    from pixparse_amd.models import get_model_config
+    cfg = get_model_config(model_name)
+    ie, td = cfg.image_encoder, cfg.text_decoder
+    if ie.name not in R.VIT_ARCHS:
+        return None
+    arch = dict(R.VIT_ARCHS[ie.name], depth=2)
+    R.VIT_ARCHS['_bench_trunc'] = arch
+    spec = R.ModelSpec('_bench_trunc', td.name, 1, td.max_length, tuple(ie.image_size), 1 if ie.image_fmt == 'L' else 3, vocab=50267)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: v.requires_grad_(True) for k, v in R.init_params(spec, 0).items()}
+    image, tokens, target = R.synthetic_sample(spec, 1)
+    ti, tt = R.shift_tokens(tokens, target)
+    P, De = arch['patch'], arch['dim']
+    N = (spec.img_size[0] // P) * (spec.img_size[1] // P) + 1
+    T, D, F, V = spec.max_length - 1, spec.dec_arch['d_model'], spec.dec_arch['ffn'], spec.vocab
+    f_fwd = 2 * (24 * N * De * De + 4 * N * N * De) + 2 * (N - 1) * (P * P * spec.in_chans) * De + \
+        (12 * T * D * D + 4 * N * D * D + 4 * T * D * F + 2 * T * T * D + 4 * T * N * D) + 2 * T * D * V
+    t0 = time.time()
+    loss = R.cruller_loss(params, spec, image, ti, tt, 'bf16', fast_attn=True)
+    loss.backward()
+    dt = time.time() - t0
+    docs_per_s = (3 * f_fwd / dt) / flops_train_per_doc
+    return {'value': round(docs_per_s, 5), 'unit': 'docs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/ref_cpu.py bf16 policy, {model_name} widths at full lengths (N={N}, T={T}), batch 1, truncated to 2 encoder '
+                      f'blocks + 1 decoder layer + LM head, one fwd+bwd = {3 * f_fwd / 1e12:.2f} TFLOP in {dt:.1f} s, '
+                      f'extrapolated by algorithmic FLOPs to the full {flops_train_per_doc / 1e12:.2f} TFLOP/doc'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='cruller_large_1280x960')
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from pixparse_amd.data import SyntheticLoaderBundle
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg, random_seed
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    import torch.distributed as dist
+
+    env = DeviceEnv()
+    assert env.device.type == 'cuda', 'bench.py needs MI355X devices'
+    assert env.world_size == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={env.world_size}'
+    random_seed(42, 0)   # same initial weights on every rank (rank-0 broadcast follows anyway)
+    cfg = TaskCrullerPretrainCfg(model_name=args.model, dtype='bfloat16', num_intervals=30, num_warmup_intervals=1, eval_frequency=10 ** 9,
+                                 opt=OptimizationCfg(learning_rate=3e-4, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm'))
+    task = TaskCrullerPretrain(cfg, env)
+    m = task.model
+    nb = args.steps + args.warmup
+    loader = SyntheticLoaderBundle(batch_size=args.batch, num_batches=nb, in_chans=m.in_chans, img_size=m.img_size,
+                                   max_length=m.max_length, vocab_size=task.vocab_size, seed=42, rank=env.global_rank)
+    task.train_setup(num_batches_per_interval=max(nb, 100))
+    task.train_interval_start()
+    it = iter(loader.loader)
+
+    def sync():
+        torch.cuda.synchronize()
+        if env.world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        task.train_step(next(it))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        task.train_step(next(it))
+    sync()
+    dt = time.perf_counter() - t0
+    if env.world_size > 1:
+        tt = torch.tensor([dt], device=env.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(task.last_loss)
+    docs = args.steps * args.batch * env.world_size
+    value = docs / dt
+    f_fwd, S = flops_per_doc(task)
+    f_train = 3.0 * f_fwd
+    step_tflops = value * f_train / 1e12 / env.world_size
+
+    out = {
+        'metric': METRIC, 'value': round(value, 4), 'unit': 'docs/s', 'n_gpus': env.world_size, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16', 'data': 'synthetic (N(0,1) images, uniform random full-length targets), random-init weights',
+        'config': {'workload': f'{args.model}: {m.cfg.image_encoder.name} @ {m.img_size[0]}x{m.img_size[1]}x{m.in_chans} + '
+                               f'{m.cfg.text_decoder.name} {m.n_layers}L, {m.max_length}-token targets, V={task.vocab_size}, '
+                               f'per-GPU batch {args.batch}, AdamW + clip-norm 1.0, dropout off',
+                   'global_batch': args.batch * env.world_size, 'parallelism': f'dp{env.world_size}',
+                   'train_tflop_per_doc': round(f_train / 1e12, 3)},
+        'loss': round(loss, 5),
+        'step_mfma_frac': round(step_tflops / PEAK_BF16_TFLOPS, 4), 'step_tflops_per_gpu': round(step_tflops, 1),
+        'activation_gb': round(m.activation_bytes() / 2 ** 30, 2),
+    }
+    if env.global_rank == 0:
+        if env.world_size == 1 and not args.no_roofline:
+            try:
+                out['roofline'] = dominant_kernel_roofline(task, args.batch)
+            except Exception as e:  # never lose the headline number to the microbench
+                out['roofline'] = {'error': repr(e)}
+        if env.world_size == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.model, f_train)
+            except Exception as e:
+                out['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(out), flush=True)
+    if env.world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,170 @@
+/* libcruller_hip.so -- C-ABI of the MI355X-native Cruller pretrain step (gfx950 only).
+ *
+ * The reference (huggingface/pixparse) has NO FFI/operator layer of its own: every op below is
+ * executed for it by timm / transformers / torch.  Each entry point therefore cites
+ * the reference call site whose arithmetic it replaces, and the third-party module that executes
+ * that arithmetic for the reference.  "ref:" paths are relative to /root/reference/src/pixparse;
+ * "hf:" = transformers/models/bart/modeling_bart.py (5.15.0).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (torch tensor .data_ptr()); nothing here allocates,
+ *     synchronises or touches the host; `stream` is a hipStream_t passed as void*.
+ *   - return 0 on success, <0 on error (crl_last_error() gives the text, thread-local).
+ *   - bf16 = raw uint16 storage; "f32"/"bf16" in a name is the storage type of that argument.
+ *   - row-major everywhere; ld* are leading dimensions in ELEMENTS.
+ */
+#ifndef CRL_H
+#define CRL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int crl_version(void);
+const char* crl_last_error(void);
+
+/* ---------------------------------------------------------------- GEMM (bf16 MFMA, fp32 accumulate)
+ * replaces torch.nn.functional.linear under autocast(bf16) and its autograd:
+ *   ref: models/image_encoder_timm.py:35-42 (timm Attention.qkv/proj, Mlp.fc1/fc2, PatchEmbed conv,
+ *        PatchMerging.reduction), hf:180-183,227-231,252 (q/k/v/out_proj), hf:381-386 (fc1/fc2),
+ *        hf:1297 (lm_head).
+ * layout:
+ *   CRL_NT  C[M,N] = A[M,K] * B[N,K]^T     forward  (B = nn.Linear weight)
+ *   CRL_NN  C[M,N] = A[M,K] * B[K,N]       dgrad    (A = dY, B = weight)
+ *   CRL_TN  C[M,N] = A[K,M]^T * B[K,N]     wgrad    (A = dY, B = X; contraction over rows)
+ * K must be a multiple of 32 for NT/NN (pad the operand); any K for TN. N and ldc multiples of 4,
+ * lda/ldb multiples of 8, operands 16-byte aligned and smaller than 4 GiB.
+ * epilogue (v = fp32 accumulator, b = bf16-rounded bias, all optional pointers may be NULL):
+ *   CRL_EPI_BF16        C(bf16)  = v + b
+ *   CRL_EPI_BF16_GELU   aux(bf16)= h = bf16(v + b);  C(bf16) = gelu_erf(h)
+ *   CRL_EPI_BF16_DGELU  C(bf16)  = bf16(v) * gelu'(aux)         (aux = saved pre-activation h, bf16)
+ *   CRL_EPI_F32_RESID   C(f32)   = resid(f32) + float(bf16(v + b))   (resid may alias C)
+ *   CRL_EPI_F32         C(f32)   = v            (beta = 0)
+ *   CRL_EPI_F32_ACC     C(f32)  += v            (beta = 1: grad accumulation)
+ */
+enum { CRL_NT = 0, CRL_NN = 1, CRL_TN = 2 };
+enum { CRL_EPI_BF16 = 0, CRL_EPI_BF16_GELU = 1, CRL_EPI_BF16_DGELU = 2, CRL_EPI_F32_RESID = 3,
+       CRL_EPI_F32 = 4, CRL_EPI_F32_ACC = 5 };
+int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
+                  const void* A, int64_t lda, const void* B, int64_t ldb,
+                  const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
+                  const float* resid, int64_t ldr, void* stream);
+
+/* column sums of a bf16 matrix into fp32 (bias gradients): out[n] (+)= sum_m X[m,n].
+ * ws: >= crl_colsum_ws_bytes(N) bytes of scratch. */
+size_t crl_colsum_ws_bytes(int64_t N);
+int crl_colsum_bf16(const void* X, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate,
+                    void* ws, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm (fp32 math, wavefront reduce)
+ * replaces F.layer_norm (autocast keeps it fp32): timm Block.norm1/norm2/norm_pre/norm,
+ * hf:652 (layernorm_embedding), hf:363,378,388 (post-LN).  y_f32 and/or y_bf16 may be NULL. */
+int crl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps,
+                      int64_t M, int64_t D, float* y_f32, void* y_bf16, float* mean, float* rstd,
+                      void* stream);
+/* dy = dy_f32 (optional) + float(dy_bf16) (optional).  dx_f32 (+)= LN'(dy) when dx_accumulate;
+ * dx_bf16 (optional) receives a bf16 copy of the final value written to dx_f32 (the accumulated
+ * sum when dx_accumulate) -- it is the gradient the next GEMM backward consumes.
+ * dgamma/dbeta are accumulated (+=) when acc_wgrad else overwritten.  ws >= crl_layernorm_bwd_ws_bytes(D). */
+size_t crl_layernorm_bwd_ws_bytes(int64_t D);
+int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, const float* gamma,
+                      const float* mean, const float* rstd, int64_t M, int64_t D,
+                      float* dx_f32, int dx_accumulate, void* dx_bf16,
+                      float* dgamma, float* dbeta, int acc_wgrad, void* ws, void* stream);
+
+/* ---------------------------------------------------------------- flash attention, head_dim 64
+ * replaces F.scaled_dot_product_attention: timm Attention (ViT global MHSA, non-causal),
+ * hf:185-257 (decoder self-attention is_causal=True, cross attention unmasked).
+ * element (b, n, h, j) of q lives at q + b*q_bs + n*q_rs + h*64 + j (strides in elements), same
+ * for k, v, o and their gradients; lse is [B, H, Nq] fp32 (natural log).  causal aligns the
+ * diagonal bottom-right (key j visible to query i iff j <= i + Nk - Nq). */
+int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                 const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
+                 float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
+/* delta: scratch [B, H, Nq] fp32.  dq/dk/dv strides as q/k/v. */
+int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                 const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
+                 const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
+                 void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
+                 void* dv, int64_t dv_bs, int64_t dv_rs,
+                 int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
+
+/* ---------------------------------------------------------------- Swin shifted-window attention
+ * replaces timm WindowAttention + roll / window_partition / window_reverse
+ * (cross-check: transformers/models/swin/modeling_swin.py:343-370,486-505,529-626).
+ * qkv: [B, Hf, Wf, 3, heads, hd] bf16 in natural NHWC token order (output of the qkv Linear),
+ * out: [B, Hf, Wf, heads*hd] bf16 in natural order; the cyclic shift, the window partition and
+ * the 0/-100 region mask are index arithmetic inside the kernel.  table: [(2w-1)^2, heads] fp32.
+ * hd must be 32 (every timm Swin). w*w <= 64. */
+int crl_swin_attn_fwd(const void* qkv, const float* table, void* out, int B, int Hf, int Wf,
+                      int heads, int w, int shift, float scale, void* stream);
+/* dtable accumulates (+=) with fp32 atomics when acc else must be zeroed by the caller first. */
+int crl_swin_attn_bwd(const void* qkv, const float* table, const void* d_out, void* dqkv,
+                      float* dtable, int B, int Hf, int Wf, int heads, int w, int shift, float scale,
+                      void* stream);
+/* PatchMerging gather: x [B,Hf,Wf,C] f32 -> y [B,Hf/2,Wf/2,4C] f32, order [(0,0),(1,0),(0,1),(1,1)];
+ * bwd scatters dy back (pure permutation). */
+int crl_patch_merge_fwd(const float* x, float* y, int B, int Hf, int Wf, int C, void* stream);
+int crl_patch_merge_bwd(const float* dy, float* dx, int B, int Hf, int Wf, int C, void* stream);
+
+/* ---------------------------------------------------------------- patch embedding glue
+ * im2row for the stride==kernel patch conv (timm PatchEmbed): image [B,C,H,W] f32 ->
+ * patches [B*gh*gw, Kp] bf16, column order (c, ph, pw) = conv weight.flatten(1), columns
+ * C*P*P..Kp-1 zero.  Only the top-left gh*P x gw*P pixels are read (floor crop). */
+int crl_im2row(const float* image, void* patches, int B, int C, int H, int W, int P, int gh, int gw,
+               int Kp, void* stream);
+/* ViT token assembly: x[b,0,:] = cls + pos[0]; x[b,1+i,:] = float(patch[b,i,:]) + pos[1+i]  (f32). */
+int crl_vit_tokens_fwd(const void* patch_bf16, const float* cls, const float* pos, float* x,
+                       int B, int Np, int D, void* stream);
+/* bwd: dpatch(bf16) = dx[b,1+i]; dpos (+)= sum_b dx[b]; dcls (+)= sum_b dx[b,0]. */
+int crl_vit_tokens_bwd(const float* dx, void* dpatch_bf16, float* dcls, float* dpos, int acc,
+                       int B, int Np, int D, void* stream);
+
+/* ---------------------------------------------------------------- decoder embedding
+ * hf:609,648-651: t = embed_tokens[ids] * 1.0 + embed_positions[arange(T) + 2]  -> f32 [B*T, D].
+ * (layernorm_embedding is then crl_layernorm_fwd).  ids int64. */
+int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out,
+                  int B, int T, int D, int pos_offset, void* stream);
+/* dtok[ids] += dt (fp32 atomics; dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt. */
+int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos,
+                  int B, int T, int D, int pos_offset, void* stream);
+
+/* ---------------------------------------------------------------- shifted-token cross-entropy
+ * ref: task/task_cruller_pretrain.py:118,251-256  nn.CrossEntropyLoss(ignore_index=-100) on bf16
+ * logits upcast to fp32; mean over targets != -100; optional / accum_steps and GradScaler scale.
+ * logits [M, ldl] bf16 (only the first V columns are read).  On return
+ *   loss[0] = mean NLL * loss_mul  (fp32), n_valid[0] = number of non-ignored rows (int32),
+ *   dlogits (may alias logits) = bf16((softmax - onehot) * grad_mul / n_valid), columns V..ldl-1 zeroed.
+ * row_loss: scratch [M] fp32. */
+int crl_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, int64_t M, int V,
+                      float loss_mul, float grad_mul, float* loss, int32_t* n_valid, float* row_loss,
+                      void* dlogits, void* stream);
+
+/* ---------------------------------------------------------------- optimiser over the flat arenas
+ * ref: task/task_cruller_pretrain.py:191-206,259-295 -> timm NativeScaler (GradScaler unscale,
+ * inf check), dispatch_clip_grad('norm') = torch clip_grad_norm_, torch.optim.AdamW(wd=0),
+ * optimizer.zero_grad().
+ * crl_grad_norm: state[0] = ||g||_2 * inv_scale, state[1] = clip coefficient
+ *   min(1, max_norm / (norm + 1e-6)) * inv_scale (or inv_scale when max_norm <= 0),
+ *   state[2] = 1.0 if any grad is inf/nan else 0.0.   ws >= crl_grad_norm_ws_bytes(). */
+size_t crl_grad_norm_ws_bytes(void);
+int crl_grad_norm(const float* g, int64_t n, float max_norm, float inv_scale, float* state, void* ws,
+                  void* stream);
+/* p,m,v updated in place with g*state[1]; skipped entirely when state[2] != 0 (GradScaler.step);
+ * p_bf16 (optional) receives the bf16 shadow of the new p; g is zeroed when zero_grad != 0. */
+int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, int step, const float* state, int zero_grad,
+              void* stream);
+/* fp32 -> bf16 cast of a flat range (initial shadow build), and strided fp32 [R,C] -> bf16 [R,Cp]
+ * with zero padded columns (padded K operands). */
+int crl_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int crl_cast_pad_bf16(const float* src, void* dst, int64_t R, int64_t C, int64_t Cp, void* stream);
+/* y_f32 (+)= float(x_bf16), elementwise (gradient joins). */
+int crl_add_bf16_to_f32(const void* x_bf16, float* y, int64_t n, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRL_H */

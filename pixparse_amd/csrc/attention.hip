@@ -1,0 +1,478 @@
+// Flash attention forward / backward for head_dim 64 on gfx950 (ViT global MHSA, BART causal
+// self-attention, encoder-decoder cross attention) -- include/crl.h: crl_attn_fwd / crl_attn_bwd.
+//
+// All three kernels use v_mfma_f32_32x32x16_bf16 with the *reduction index of the following
+// product kept in the accumulator registers* so that no probability tile ever crosses LDS
+// (guide §3 "An accumulator tile as the next MFMA's operand"):
+//   fwd   : S^T = K.Q^T  (query on the lane, keys in registers) -> softmax per lane ->
+//           O^T += V^T.P^T   (V^T fragments by ds_read_b64_tr_b16 from the row-major V tile)
+//   dK/dV : S = Q.K^T, dP = dO.V^T (key on the lane, queries in registers) ->
+//           dV^T += dO^T.P, dK^T += Q^T.dS   (Q^T/dO^T by transposed LDS reads)
+//   dQ    : S^T = K.Q^T, dP^T = V.dO^T (query on the lane) -> dQ^T += K^T.dS^T
+// dQ is a second pass that recomputes S and dP (7 products instead of 5): deterministic and free
+// of float atomics -- at N = 6189 an atomic dQ would be bound by the ~1.3 TB/s chip-wide atomic
+// rate (DESIGN.md "attention backward").
+// Tiles of 64 rows x 64 bf16 (128-B rows) are staged by bounds-checked LDS-DMA (rows past the end
+// of the sequence arrive as zeros) with one XOR swizzle that is conflict-free for BOTH the
+// ds_read_b128 row reads and the transposed reads.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnArgs {
+  const u16 *q, *k, *v, *o, *d_o;
+  u16 *out, *dq, *dk, *dv;
+  float* lse;          // fwd: written; bwd: read
+  float* delta;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+  int B, H, Nq, Nk, causal;
+  float scale;
+  int nqt, nkt;
+};
+
+__device__ __forceinline__ int swz64(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// stage 64 rows x 64 bf16 starting at row `row0` of a [*, rs]-strided matrix into an 8-KB LDS tile
+__device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs_, char* lds, int row0, int64_t rs, int tid, int wave) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c = it * 256 + tid;
+    const int row = c >> 3, pc = c & 7;
+    const int lc = pc ^ swz64(row);
+    const uint32_t off = (uint32_t)(((int64_t)(row0 + row) * rs + lc * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, LDS_PTR(lds + (it * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+// MFMA 32x32x16 operand whose k index is contiguous in the tile row: rows rowbase..+31, k = 16ks + 8h + j
+__device__ __forceinline__ bf16x8 frag_row(const char* lds, int rowbase, int ks, int lane) {
+  const int row = rowbase + (lane & 31);
+  const int chunk = 2 * ks + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ swz64(row)) << 4));
+}
+// MFMA 32x32x16 operand whose k index is the tile ROW: operand row = tile column 32db + (lane&31),
+// element j of lane half h = tile row kbase + 8(j>>2) + 4h + (j&3)  (the accumulator k order)
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int kbase, int db, int lane) {
+  const int G = lane >> 4, idx = lane & 15, qq = idx >> 2, p = idx & 3, hh = lane >> 5;
+  const int col = 32 * db + 16 * (G & 1) + 4 * p;
+  const int r1 = kbase + 4 * hh + qq, r2 = r1 + 8;
+  const int a1 = r1 * 128 + (((col >> 3) ^ swz64(r1)) << 4) + (col & 7) * 2;
+  const int a2 = r2 * 128 + (((col >> 3) ^ swz64(r2)) << 4) + (col & 7) * 2;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a1));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a2));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);
+}
+// registers 8s..8s+7 of a 32x32 accumulator as the next product's operand
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)x[8 * s + j];
+  return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// row index (within a 32-row block) of accumulator register r for lane half hh
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ void block_to_bh_tile(int bid, int ntile, int BH, int& bh, int& tile) {
+  if ((BH & 7) == 0) {  // heads of one (b,h) stay on one XCD (blocks b, b+8 share an XCD): K/V reuse in its L2
+    const int x = bid & 7, r = bid >> 3;
+    bh = x + 8 * (r / ntile);
+    tile = r % ntile;
+  } else {
+    bh = bid / ntile;
+    tile = bid % ntile;
+  }
+}
+
+// ======================================================================================= forward
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31, hh = lane >> 5;
+  int bh, qt;
+  block_to_bh_tile(blockIdx.x, a.nqt, a.B * a.H, bh, qt);
+  const int b = bh / a.H, h = bh % a.H;
+  const int off = a.Nk - a.Nq;
+
+  const u16* qp = a.q + b * a.q_bs + h * 64;
+  const u16* kp = a.k + b * a.k_bs + h * 64;
+  const u16* vp = a.v + b * a.v_bs + h * 64;
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kp, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vp, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+
+  const int q0 = qt * 128 + wave * 32;
+  const int qrow = min(q0 + qi, a.Nq - 1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)qrow * a.q_rs + 16 * ks + 8 * hh);
+
+  int kend = a.Nk;
+  if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
+  const int nt = kend > 0 ? (kend + 63) / 64 : 0;
+
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m = -INFINITY, l = 0.f;
+  const float c = a.scale * LOG2E;
+  const int qabs = q0 + qi;
+
+  if (nt > 0) { stage64(rk, smem, 0, a.k_rs, tid, wave); stage64(rv, smem + 8192, 0, a.v_rs, tid, wave); }
+  for (int kt = 0; kt < nt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int buf = kt & 1;
+    if (kt + 1 < nt) {
+      stage64(rk, smem + (buf ^ 1) * 16384, (kt + 1) * 64, a.k_rs, tid, wave);
+      stage64(rv, smem + (buf ^ 1) * 16384 + 8192, (kt + 1) * 64, a.v_rs, tid, wave);
+    }
+    const char* kl = smem + buf * 16384;
+    const char* vl = kl + 8192;
+    const int k0 = kt * 64;
+    f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s0 = mfma32(frag_row(kl, 0, ks, lane), qf[ks], s0);
+      s1 = mfma32(frag_row(kl, 32, ks, lane), qf[ks], s1);
+    }
+    // ---- online softmax, query on the lane, this lane holds 2 x 16 of the tile's 64 keys
+    const bool need_mask = (k0 + 64 > a.Nk) || (CAUSAL && (k0 + 63 > q0 + off));
+    if (need_mask) {
+      const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + acc_row(r, hh);
+        if (key > lim) s0[r] = -INFINITY;
+        if (key + 32 > lim) s1[r] = -INFINITY;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx * c);          // scores scaled into the log2 domain (c > 0)
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+    m = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -m_use));
+      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -m_use));
+      ps += s0[r] + s1[r];
+    }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 p0 = acc_frag(s0, s), p1 = acc_frag(s1, s);
+      o0 = mfma32(frag_tr(vl, 16 * s, 0, lane), p0, o0);
+      o1 = mfma32(frag_tr(vl, 16 * s, 1, lane), p0, o1);
+      o0 = mfma32(frag_tr(vl, 32 + 16 * s, 0, lane), p1, o0);
+      o1 = mfma32(frag_tr(vl, 32 + 16 * s, 1, lane), p1, o1);
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (qabs < a.Nq) {
+    u16* op = a.out + b * a.o_bs + (int64_t)qabs * a.o_rs + h * 64;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dv = 8 * g4 + 4 * hh;
+      *reinterpret_cast<uint2*>(op + dv) = uint2{pack_bf2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv), pack_bf2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv)};
+      *reinterpret_cast<uint2*>(op + 32 + dv) = uint2{pack_bf2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv), pack_bf2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv)};
+    }
+    if (hh == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qabs] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : -INFINITY;
+  }
+}
+
+// ======================================================================================= delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & 7);
+  const int64_t r = gid >> 3;  // over B*H*Nq
+  const int64_t total = (int64_t)a.B * a.H * a.Nq;
+  float s = 0.f;
+  if (r < total) {
+    const int qn = (int)(r % a.Nq);
+    const int bh = (int)(r / a.Nq);
+    const int b = bh / a.H, h = bh % a.H;
+    const uint4 x = *reinterpret_cast<const uint4*>(a.o + b * a.o_bs + (int64_t)qn * a.o_rs + h * 64 + sub * 8);
+    const uint4 y = *reinterpret_cast<const uint4*>(a.d_o + b * a.do_bs + (int64_t)qn * a.do_rs + h * 64 + sub * 8);
+    const uint32_t xw[4] = {x.x, x.y, x.z, x.w}, yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += bf2f(xw[j] & 0xffff) * bf2f(yw[j] & 0xffff) + bf2f(xw[j] >> 16) * bf2f(yw[j] >> 16);
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (r < total && sub == 0) a.delta[r] = s;
+}
+
+// ======================================================================================= dK, dV
+// workgroup = 128 keys of one (b,h) (32 per wave, K/V fragments in registers), sweeps query tiles of 64.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (2 * 8192 + 512)];  // [buf][Q | dO | lse*log2e(64) | delta(64)]
+  constexpr int BUF = 2 * 8192 + 512;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ki = lane & 31, hh = lane >> 5;
+  int bh, ktile;
+  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, ktile);
+  const int b = bh / a.H, h = bh % a.H;
+  const int off = a.Nk - a.Nq;
+
+  const u16* qp = a.q + b * a.q_bs + h * 64;
+  const u16* dop = a.d_o + b * a.do_bs + h * 64;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qp, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dop, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
+  const float* lsep = a.lse + ((int64_t)b * a.H + h) * a.Nq;
+  const float* delp = a.delta + ((int64_t)b * a.H + h) * a.Nq;
+
+  const int key0 = ktile * 128 + wave * 32;
+  const int kabs = key0 + ki;
+  const int krow = min(kabs, a.Nk - 1);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(a.k + b * a.k_bs + (int64_t)krow * a.k_rs + h * 64 + 16 * ks + 8 * hh);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(a.v + b * a.v_bs + (int64_t)krow * a.v_rs + h * 64 + 16 * ks + 8 * hh);
+  }
+  // causal: key j is seen by queries i >= j - off
+  int qstart_tile = 0;
+  if (CAUSAL) qstart_tile = max(0, ktile * 128 - off) / 64;
+  const int nqt64 = (a.Nq + 63) / 64;
+
+  f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+  const float c = a.scale * LOG2E;
+
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(lsep, (uint32_t)a.Nq * 4u);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(delp, (uint32_t)a.Nq * 4u);
+  auto stage = [&](int buf, int t) {
+    char* base = smem + buf * BUF;
+    stage64(rq, base, t * 64, a.q_rs, tid, wave);
+    stage64(rdo, base + 8192, t * 64, a.do_rs, tid, wave);
+    // 64 lse + 64 delta values of the tile by 4-byte LDS-DMA (rows past Nq arrive as 0; their Q and dO rows are 0 too)
+    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, LDS_PTR(base + 16384), 4, (uint32_t)(t * 64 + lane) * 4u, 0, 0, 0);
+    else if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(base + 16384 + 256), 4, (uint32_t)(t * 64 + lane) * 4u, 0, 0, 0);
+  };
+
+  if (qstart_tile < nqt64) stage(0, qstart_tile);
+  for (int t = qstart_tile; t < nqt64; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int buf = (t - qstart_tile) & 1;
+    if (t + 1 < nqt64) stage(buf ^ 1, t + 1);
+    const char* ql = smem + buf * BUF;
+    const char* dol = ql + 8192;
+    const float* lse_s = reinterpret_cast<const float*>(ql + 16384);
+    const float* del_s = lse_s + 64;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(frag_row(ql, 32 * qb, ks, lane), kf[ks], s);
+        dp = mfma32(frag_row(dol, 32 * qb, ks, lane), vf[ks], dp);
+      }
+      const int qbase = t * 64 + 32 * qb;
+      const bool need_mask = CAUSAL && (key0 + 31 > qbase + off);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+        const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
+        const float Lv[4] = {L.x * LOG2E, L.y * LOG2E, L.z * LOG2E, L.w * LOG2E}, Dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g4 + i;
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lv[i]));
+          if (need_mask && (kabs > qbase + 8 * g4 + 4 * hh + i + off)) p = 0.f;
+          s[r] = p;
+          dp[r] = p * (dp[r] - Dv[i]);
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = acc_frag(s, ss), dsf = acc_frag(dp, ss);
+        dv0 = mfma32(frag_tr(dol, 32 * qb + 16 * ss, 0, lane), pf, dv0);
+        dv1 = mfma32(frag_tr(dol, 32 * qb + 16 * ss, 1, lane), pf, dv1);
+        dk0 = mfma32(frag_tr(ql, 32 * qb + 16 * ss, 0, lane), dsf, dk0);
+        dk1 = mfma32(frag_tr(ql, 32 * qb + 16 * ss, 1, lane), dsf, dk1);
+      }
+    }
+  }
+  if (kabs < a.Nk) {
+    u16* dkp = a.dk + b * a.dk_bs + (int64_t)kabs * a.dk_rs + h * 64;
+    u16* dvp = a.dv + b * a.dv_bs + (int64_t)kabs * a.dv_rs + h * 64;
+    const float sc = a.scale;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = 8 * g4 + 4 * hh;
+      *reinterpret_cast<uint2*>(dkp + d) = uint2{pack_bf2(dk0[4 * g4] * sc, dk0[4 * g4 + 1] * sc), pack_bf2(dk0[4 * g4 + 2] * sc, dk0[4 * g4 + 3] * sc)};
+      *reinterpret_cast<uint2*>(dkp + 32 + d) = uint2{pack_bf2(dk1[4 * g4] * sc, dk1[4 * g4 + 1] * sc), pack_bf2(dk1[4 * g4 + 2] * sc, dk1[4 * g4 + 3] * sc)};
+      *reinterpret_cast<uint2*>(dvp + d) = uint2{pack_bf2(dv0[4 * g4], dv0[4 * g4 + 1]), pack_bf2(dv0[4 * g4 + 2], dv0[4 * g4 + 3])};
+      *reinterpret_cast<uint2*>(dvp + 32 + d) = uint2{pack_bf2(dv1[4 * g4], dv1[4 * g4 + 1]), pack_bf2(dv1[4 * g4 + 2], dv1[4 * g4 + 3])};
+    }
+  }
+}
+
+// ======================================================================================= dQ
+// workgroup = 128 queries (32 per wave, Q/dO fragments in registers), sweeps key tiles of 64.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31, hh = lane >> 5;
+  int bh, qt;
+  block_to_bh_tile(blockIdx.x, a.nqt, a.B * a.H, bh, qt);
+  const int b = bh / a.H, h = bh % a.H;
+  const int off = a.Nk - a.Nq;
+
+  const u16* kp = a.k + b * a.k_bs + h * 64;
+  const u16* vp = a.v + b * a.v_bs + h * 64;
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kp, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vp, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+
+  const int q0 = qt * 128 + wave * 32;
+  const int qabs = q0 + qi;
+  const int qrow = min(qabs, a.Nq - 1);
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(a.q + b * a.q_bs + (int64_t)qrow * a.q_rs + h * 64 + 16 * ks + 8 * hh);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(a.d_o + b * a.do_bs + (int64_t)qrow * a.do_rs + h * 64 + 16 * ks + 8 * hh);
+  }
+  const float L = a.lse[((int64_t)b * a.H + h) * a.Nq + qrow] * LOG2E;
+  const float Dl = a.delta[((int64_t)b * a.H + h) * a.Nq + qrow];
+
+  int kend = a.Nk;
+  if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
+  const int nt = kend > 0 ? (kend + 63) / 64 : 0;
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  const float c = a.scale * LOG2E;
+
+  if (nt > 0) { stage64(rk, smem, 0, a.k_rs, tid, wave); stage64(rv, smem + 8192, 0, a.v_rs, tid, wave); }
+  for (int kt = 0; kt < nt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int buf = kt & 1;
+    if (kt + 1 < nt) {
+      stage64(rk, smem + (buf ^ 1) * 16384, (kt + 1) * 64, a.k_rs, tid, wave);
+      stage64(rv, smem + (buf ^ 1) * 16384 + 8192, (kt + 1) * 64, a.v_rs, tid, wave);
+    }
+    const char* kl = smem + buf * 16384;
+    const char* vl = kl + 8192;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(frag_row(kl, 32 * kb, ks, lane), qf[ks], s);
+        dp = mfma32(frag_row(vl, 32 * kb, ks, lane), dof[ks], dp);
+      }
+      const bool need_mask = (k0 + 32 * kb + 32 > a.Nk) || (CAUSAL && (k0 + 32 * kb + 31 > q0 + off));
+      const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L));
+        if (need_mask && (k0 + 32 * kb + acc_row(r, hh) > lim)) p = 0.f;  // also keeps exp(-lse) of zero-filled keys out
+        dp[r] = p * (dp[r] - Dl);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 dsf = acc_frag(dp, ss);
+        dq0 = mfma32(frag_tr(kl, 32 * kb + 16 * ss, 0, lane), dsf, dq0);
+        dq1 = mfma32(frag_tr(kl, 32 * kb + 16 * ss, 1, lane), dsf, dq1);
+      }
+    }
+  }
+  if (qabs < a.Nq) {
+    u16* dqp = a.dq + b * a.dq_bs + (int64_t)qabs * a.dq_rs + h * 64;
+    const float sc = a.scale;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = 8 * g4 + 4 * hh;
+      *reinterpret_cast<uint2*>(dqp + d) = uint2{pack_bf2(dq0[4 * g4] * sc, dq0[4 * g4 + 1] * sc), pack_bf2(dq0[4 * g4 + 2] * sc, dq0[4 * g4 + 3] * sc)};
+      *reinterpret_cast<uint2*>(dqp + 32 + d) = uint2{pack_bf2(dq1[4 * g4] * sc, dq1[4 * g4 + 1] * sc), pack_bf2(dq1[4 * g4 + 2] * sc, dq1[4 * g4 + 3] * sc)};
+    }
+  }
+}
+
+int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) {
+  CRL_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "%s: empty problem", who);
+  CRL_CHECK(rs_min >= 64, "%s: row stride must be >= 64 elements", who);
+  return 0;
+}
+#define CHK_STRIDE(name, p, bs, rs)                                                                         \
+  CRL_CHECK(((uintptr_t)(p) % 16) == 0 && ((bs) % 8) == 0 && ((rs) % 8) == 0, "%s: " name " must be 16-byte aligned with strides multiple of 8", who)
+#define CHK_EXTENT(name, n, rs) CRL_CHECK((uint64_t)((n) + 64) * (uint64_t)(rs) * 2 < (1ull << 32), "%s: " name " per-batch extent exceeds 4 GiB", who)
+
+}  // namespace
+
+extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                            const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
+                            float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream) {
+  const char* who = "crl_attn_fwd";
+  if (check_common(who, B, H, Nq, Nk, q_rs < k_rs ? (q_rs < v_rs ? q_rs : v_rs) : (k_rs < v_rs ? k_rs : v_rs))) return -1;
+  CRL_CHECK(q && k && v && o && lse, "%s: null pointer", who);
+  CHK_STRIDE("q", q, q_bs, q_rs); CHK_STRIDE("k", k, k_bs, k_rs); CHK_STRIDE("v", v, v_bs, v_rs); CHK_STRIDE("o", o, o_bs, o_rs);
+  CHK_EXTENT("k", Nk, k_rs); CHK_EXTENT("v", Nk, v_rs);
+  AttnArgs a{};
+  a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.out = (u16*)o; a.lse = lse;
+  a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
+  a.nqt = (Nq + 127) / 128;
+  const unsigned grid = (unsigned)a.nqt * B * H;
+  if (causal) attn_fwd_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
+  else attn_fwd_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a);
+  CRL_LAUNCH_CHECK(who);
+  return 0;
+}
+
+extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                            const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
+                            const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
+                            void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
+                            void* dv, int64_t dv_bs, int64_t dv_rs, int B, int H, int Nq, int Nk, float scale, int causal,
+                            void* stream) {
+  const char* who = "crl_attn_bwd";
+  if (check_common(who, B, H, Nq, Nk, 64)) return -1;
+  CRL_CHECK(q && k && v && o && d_o && lse && delta && dq && dk && dv, "%s: null pointer", who);
+  CHK_STRIDE("q", q, q_bs, q_rs); CHK_STRIDE("k", k, k_bs, k_rs); CHK_STRIDE("v", v, v_bs, v_rs); CHK_STRIDE("o", o, o_bs, o_rs);
+  CHK_STRIDE("do", d_o, do_bs, do_rs); CHK_STRIDE("dq", dq, dq_bs, dq_rs); CHK_STRIDE("dk", dk, dk_bs, dk_rs); CHK_STRIDE("dv", dv, dv_bs, dv_rs);
+  CHK_EXTENT("k", Nk, k_rs); CHK_EXTENT("v", Nk, v_rs); CHK_EXTENT("q", Nq, q_rs); CHK_EXTENT("do", Nq, do_rs);
+  AttnArgs a{};
+  a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.o = (const u16*)o; a.d_o = (const u16*)d_o;
+  a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
+  a.do_bs = do_bs; a.do_rs = do_rs; a.dq_bs = dq_bs; a.dq_rs = dq_rs; a.dk_bs = dk_bs; a.dk_rs = dk_rs; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
+  a.nqt = (Nq + 127) / 128; a.nkt = (Nk + 127) / 128;
+  hipStream_t s = as_stream(stream);
+  const int64_t rows = (int64_t)B * H * Nq;
+  attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
+  CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
+  const unsigned gk = (unsigned)a.nkt * B * H, gq = (unsigned)a.nqt * B * H;
+  if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
+  CRL_LAUNCH_CHECK("crl_attn_bwd(dkdv)");
+  if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
+  CRL_LAUNCH_CHECK("crl_attn_bwd(dq)");
+  return 0;
+}

@@ -1,0 +1,80 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libcruller_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/crl.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+extern "C" void crl_set_error(const char* fmt, ...);
+
+#define CRL_CHECK(cond, ...)                 \
+  do {                                       \
+    if (!(cond)) {                           \
+      crl_set_error(__VA_ARGS__);            \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+#define CRL_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      crl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(u16 x) { return __uint_as_float(((uint32_t)x) << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+__device__ __forceinline__ u16 f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// exact (erf) GELU and its derivative, fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave64 reductions ----------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- buffer resource (raw, bounds-checked: out-of-range 16-B loads return zeros) --------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD a contiguous chunk of the logical tile order (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

@@ -1,0 +1,265 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 -- the Linear / conv-as-GEMM / LM-head forward,
+// dgrad and wgrad of the Cruller step (include/crl.h: crl_gemm_bf16).
+//
+// Structure (guide §5 "minimum 2-phase"): 128x128 output tile per 256-thread workgroup (4 waves,
+// 2x2, 64x64 per wave = 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 64 (32 for K % 64 != 0),
+// two LDS stages filled by bounds-checked LDS-DMA (`buffer_load_dwordx4 ... lds`: rows past the
+// end of a matrix arrive as zeros, which is what makes ragged M / ragged contraction exact),
+// one barrier per K tile.  Two LDS images:
+//   KM  [128 rows][BK k]   (operand stored with k contiguous) read with ds_read_b128,
+//   TR  [BK k][128 cols]   (operand stored with k as the ROW index) read with ds_read_b64_tr_b16,
+// both XOR-swizzled on the DMA *source* side (LDS destination stays lane-linear, guide rule 21).
+// The MFMA A operand is the matrix-B fragment (n on the row index) and the MFMA B operand is the
+// matrix-A fragment, so every lane ends up with 4 consecutive n of one output row -> 8/16-byte
+// row-contiguous epilogue stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT_THREADS = 256;
+
+struct GemmArgs {
+  const u16* A; const u16* B; const float* bias; void* C; void* aux; const float* resid;
+  int M, N, K;
+  int lda, ldb, ldc, ldaux, ldr;
+  uint32_t a_bytes, b_bytes;
+  int ntm, ntn;
+};
+
+// ---- swizzles (see the bank analysis in DESIGN.md "GEMM LDS images") ----
+template <int BK> __device__ __forceinline__ int km_swz(int row) {
+  return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+__device__ __forceinline__ int tr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// Issue the LDS-DMA for one operand tile.  KM: tile rows = matrix rows r0.., k contiguous from k0.
+template <int BK>
+__device__ __forceinline__ void stage_km(__amdgpu_buffer_rsrc_t rs, char* lds, int r0, int k0, int ld,
+                                         int tid, int wave) {
+  constexpr int CPR = BK / 8;                   // 16-B chunks per row
+  constexpr int NCH = 128 * CPR / NT_THREADS;   // chunks per thread
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = it * NT_THREADS + tid;
+    const int row = c / CPR, ps = c % CPR;
+    const int ls = ps ^ km_swz<BK>(row);
+    const uint32_t off = ((uint32_t)(r0 + row) * (uint32_t)ld + (uint32_t)(k0 + ls * 8)) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+// TR: tile rows = contraction index k0.., columns c0.. of the matrix (128 of them).
+template <int BK>
+__device__ __forceinline__ void stage_tr(__amdgpu_buffer_rsrc_t rs, char* lds, int k0, int c0, int ld,
+                                         int tid, int wave) {
+  constexpr int NCH = BK * 16 / NT_THREADS;
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = it * NT_THREADS + tid;
+    const int row = c >> 4, pc = c & 15;
+    const int lc = pc ^ tr_swz(row);
+    const uint32_t off = ((uint32_t)(k0 + row) * (uint32_t)ld + (uint32_t)(c0 + lc * 8)) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+
+// fragment (8 bf16 along k) for the 16 rows/cols [base, base+16) of a staged tile, k-step ks
+template <int BK>
+__device__ __forceinline__ bf16x8 frag_km(const char* lds, int base, int ks, int lane) {
+  const int row = base + (lane & 15), g = lane >> 4;
+  const int slot = ks * 4 + g;
+  const int addr = row * (BK * 2) + ((slot ^ km_swz<BK>(row)) << 4);
+  return *reinterpret_cast<const bf16x8*>(lds + addr);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int base, int ks, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = base + 4 * p;
+  const int k1 = ks * 32 + 8 * g + q;
+  const int a1 = k1 * 256 + ((((col >> 3)) ^ tr_swz(k1)) << 4) + (col & 7) * 2;
+  const int k2 = k1 + 4;
+  const int a2 = k2 * 256 + ((((col >> 3)) ^ tr_swz(k2)) << 4) + (col & 7) * 2;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a1));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a2));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int LAYOUT, int EPI, int BK>
+__global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * BK * 2];
+  constexpr int TILE_BYTES = 128 * BK * 2;
+  constexpr bool A_TR = (LAYOUT == CRL_TN);
+  constexpr bool B_TR = (LAYOUT != CRL_NT);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = t / g.ntn, tn = t % g.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, g.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.B, g.b_bytes);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + BK - 1) / BK;
+
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * 2 * TILE_BYTES;
+    char* lb = la + TILE_BYTES;
+    if constexpr (A_TR) stage_tr<BK>(ra, la, kt * BK, m0, g.lda, tid, wave);
+    else stage_km<BK>(ra, la, m0, kt * BK, g.lda, tid, wave);
+    if constexpr (B_TR) stage_tr<BK>(rb, lb, kt * BK, n0, g.ldb, tid, wave);
+    else stage_km<BK>(rb, lb, n0, kt * BK, g.ldb, tid, wave);
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* la = smem + cur * 2 * TILE_BYTES;
+    const char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_TR) fa[i] = frag_tr(la, wm * 64 + i * 16, ks, lane);
+        else fa[i] = frag_km<BK>(la, wm * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (B_TR) fb[j] = frag_tr(lb, wn * 64 + j * 16, ks, lane);
+        else fb[j] = frag_km<BK>(lb, wn * 64 + j * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (i = lane&15, q = lane>>4) holds C[m = .. + i][n = .. + 4q + 0..3]
+  const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lq * 4;
+      if (n >= g.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (EPI == CRL_EPI_BF16 || EPI == CRL_EPI_BF16_GELU || EPI == CRL_EPI_F32_RESID) {
+        if (g.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+          v[0] += round_bf(b.x); v[1] += round_bf(b.y); v[2] += round_bf(b.z); v[3] += round_bf(b.w);
+        }
+      }
+      if constexpr (EPI == CRL_EPI_BF16) {
+        uint2 o{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = o;
+      } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
+        float h[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
+        *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+        *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+      } else if constexpr (EPI == CRL_EPI_BF16_DGELU) {
+        const uint2 hh = *reinterpret_cast<const uint2*>((const u16*)g.aux + (size_t)m * g.ldaux + n);
+        const float h0 = bf2f(hh.x & 0xffff), h1 = bf2f(hh.x >> 16), h2 = bf2f(hh.y & 0xffff), h3 = bf2f(hh.y >> 16);
+        const float y0 = round_bf(v[0]) * dgelu_f(h0), y1 = round_bf(v[1]) * dgelu_f(h1);
+        const float y2 = round_bf(v[2]) * dgelu_f(h2), y3 = round_bf(v[3]) * dgelu_f(h3);
+        *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y0, y1), pack_bf2(y2, y3)};
+      } else if constexpr (EPI == CRL_EPI_F32_RESID) {
+        const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+        float4 o{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
+        *reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n) = o;
+      } else if constexpr (EPI == CRL_EPI_F32) {
+        *reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
+      } else {  // CRL_EPI_F32_ACC
+        float4* p = reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n);
+        float4 o = *p;
+        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+        *p = o;
+      }
+    }
+  }
+}
+
+template <int LAYOUT, int EPI>
+int launch_bk(const GemmArgs& a, int bk, hipStream_t s) {
+  const int grid = a.ntm * a.ntn;
+  if (bk == 64) gemm_kernel<LAYOUT, EPI, 64><<<grid, NT_THREADS, 0, s>>>(a);
+  else gemm_kernel<LAYOUT, EPI, 32><<<grid, NT_THREADS, 0, s>>>(a);
+  CRL_LAUNCH_CHECK("crl_gemm_bf16");
+  return 0;
+}
+
+template <int LAYOUT>
+int launch_epi(const GemmArgs& a, int epi, int bk, hipStream_t s) {
+  switch (epi) {
+    case CRL_EPI_BF16: return launch_bk<LAYOUT, CRL_EPI_BF16>(a, bk, s);
+    case CRL_EPI_BF16_GELU: return launch_bk<LAYOUT, CRL_EPI_BF16_GELU>(a, bk, s);
+    case CRL_EPI_BF16_DGELU: return launch_bk<LAYOUT, CRL_EPI_BF16_DGELU>(a, bk, s);
+    case CRL_EPI_F32_RESID: return launch_bk<LAYOUT, CRL_EPI_F32_RESID>(a, bk, s);
+    case CRL_EPI_F32: return launch_bk<LAYOUT, CRL_EPI_F32>(a, bk, s);
+    case CRL_EPI_F32_ACC: return launch_bk<LAYOUT, CRL_EPI_F32_ACC>(a, bk, s);
+  }
+  crl_set_error("crl_gemm_bf16: bad epilogue %d", epi);
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
+                             const void* A, int64_t lda, const void* B, int64_t ldb,
+                             const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
+                             const float* resid, int64_t ldr, void* stream) {
+  CRL_CHECK(M > 0 && N > 0 && K > 0, "crl_gemm_bf16: empty problem %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
+  CRL_CHECK(A && B && C, "crl_gemm_bf16: null operand");
+  CRL_CHECK((N % 4) == 0 && (ldc % 4) == 0, "crl_gemm_bf16: N (%lld) and ldc (%lld) must be multiples of 4", (long long)N, (long long)ldc);
+  CRL_CHECK((lda % 8) == 0 && (ldb % 8) == 0, "crl_gemm_bf16: lda/ldb must be multiples of 8 (16-byte rows)");
+  CRL_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "crl_gemm_bf16: operands must be 16-byte aligned");
+  int bk = 64;
+  int64_t a_rows, a_cols, b_rows, b_cols;
+  if (layout == CRL_NT) { a_rows = M; a_cols = K; b_rows = N; b_cols = K; }
+  else if (layout == CRL_NN) { a_rows = M; a_cols = K; b_rows = K; b_cols = N; }
+  else if (layout == CRL_TN) { a_rows = K; a_cols = M; b_rows = K; b_cols = N; }
+  else { crl_set_error("crl_gemm_bf16: bad layout %d", layout); return -1; }
+  if (layout != CRL_TN) {
+    CRL_CHECK((K % 32) == 0, "crl_gemm_bf16: K (%lld) must be a multiple of 32 for NT/NN", (long long)K);
+    if (K % 64) bk = 32;
+  }
+  CRL_CHECK(lda >= a_cols && ldb >= b_cols, "crl_gemm_bf16: leading dimension smaller than the row");
+  if (epilogue == CRL_EPI_BF16_GELU || epilogue == CRL_EPI_BF16_DGELU) CRL_CHECK(aux != nullptr && (ldaux % 4) == 0, "crl_gemm_bf16: aux required");
+  if (epilogue == CRL_EPI_F32_RESID) CRL_CHECK(resid != nullptr && (ldr % 4) == 0, "crl_gemm_bf16: resid required");
+  const uint64_t ab = (uint64_t)((a_rows - 1) * lda + a_cols) * 2, bb = (uint64_t)((b_rows - 1) * ldb + b_cols) * 2;
+  // DMA offsets are 32-bit and tiles may overhang by up to 127 rows
+  CRL_CHECK((uint64_t)(a_rows + 128) * lda * 2 < (1ull << 32) && (uint64_t)(b_rows + 128) * ldb * 2 < (1ull << 32),
+            "crl_gemm_bf16: operand larger than 4 GiB");
+  GemmArgs a;
+  a.A = (const u16*)A; a.B = (const u16*)B; a.bias = bias; a.C = C; a.aux = aux; a.resid = resid;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc; a.ldaux = (int)ldaux; a.ldr = (int)ldr;
+  a.a_bytes = (uint32_t)ab; a.b_bytes = (uint32_t)bb;
+  a.ntm = (int)((M + BM - 1) / BM); a.ntn = (int)((N + BN - 1) / BN);
+  hipStream_t s = as_stream(stream);
+  switch (layout) {
+    case CRL_NT: return launch_epi<CRL_NT>(a, epilogue, bk, s);
+    case CRL_NN: return launch_epi<CRL_NN>(a, epilogue, bk, s);
+    default: return launch_epi<CRL_TN>(a, epilogue, bk, s);
+  }
+}

@@ -1,0 +1,2 @@
+from .preprocess import preprocess_ocr_anno, preprocess_text_anno, mask_targets
+from .synthetic import SyntheticLoaderBundle, synthetic_batch

@@ -1,0 +1,61 @@
+"""Synthetic loader with the LoaderBundle surface the app / framework touch (.loader, .num_batches,
+.num_samples, .set_interval) -- ref: data/loader.py:24-119, app/train.py:57,183.  Inputs follow SURVEY §8d:
+image ~ N(0,1) (stands for normalised pixels), full-length random targets, <s_pretrain> first, eos last."""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .preprocess import mask_targets
+
+
+def synthetic_batch(batch_size, in_chans, img_size, max_length, vocab_size, seed=42, rank=0, ragged=False, pin=False):
+    gen = torch.Generator().manual_seed(seed + rank)
+    H, W = img_size
+    image = torch.randn(batch_size, in_chans, H, W, generator=gen)
+    hi = min(50265, vocab_size - 2)
+    tokens = torch.randint(3, hi, (batch_size, max_length), generator=gen)
+    tokens[:, 0] = vocab_size - 1          # <s_pretrain>: last added token
+    tokens[:, max_length - 1] = 2          # eos
+    if ragged:
+        for b in range(batch_size):
+            n = int(torch.randint(max_length // 2, max_length, (1,), generator=gen))
+            tokens[b, n] = 2
+            tokens[b, n + 1:] = 1
+    target = torch.stack([mask_targets(t, 1, vocab_size - 1) for t in tokens])
+    if pin and torch.cuda.is_available():
+        image, tokens, target = image.pin_memory(), tokens.pin_memory(), target.pin_memory()
+    return image, tokens, target
+
+
+class _Iter:
+    def __init__(self, bundle):
+        self.b = bundle
+
+    def __iter__(self):
+        for i in range(self.b.num_batches):
+            yield self.b.samples[i % len(self.b.samples)]
+
+
+@dataclass
+class SyntheticLoaderBundle:
+    batch_size: int
+    num_batches: int
+    in_chans: int
+    img_size: tuple
+    max_length: int
+    vocab_size: int
+    seed: int = 42
+    rank: int = 0
+    distinct: int = 2
+    ragged: bool = False
+    sampler: Optional[object] = None
+
+    def __post_init__(self):
+        self.samples = [synthetic_batch(self.batch_size, self.in_chans, self.img_size, self.max_length, self.vocab_size,
+                                        self.seed + 1000 * i, self.rank, self.ragged, pin=True) for i in range(self.distinct)]
+        self.num_samples = self.num_batches * self.batch_size
+        self.loader = _Iter(self)
+
+    def set_interval(self, i: int):
+        self.interval = i

@@ -1,0 +1,63 @@
+"""Bucketed gradient all-reduce over the flat gradient arena (replaces DistributedDataParallel's
+reducer, ref: task/task_cruller_pretrain.py:181-189,280-283).
+
+The arena is laid out in forward order, so backward completes it from the end towards the start.
+Buckets are contiguous slices cut from the END of the arena; ``on_ready(name)`` (called by the
+backward sweep) launches the asynchronous all-reduce of every bucket that lies entirely at or after
+entry ``name``.  With the RCCL backend each all-reduce runs on the process group's own stream and
+is ordered after the kernels already enqueued on the compute stream, so communication overlaps the
+rest of backward; ``finish()`` makes the compute stream wait for all of them.  The sum is NOT
+divided here: 1/world_size is folded into the unscale/clip coefficient of the optimiser kernel.
+xGMI is a full mesh of point-to-point links, so buckets are large (default 64 MiB) -- few, big
+collectives -- rather than DDP's 25 MiB.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradReducer:
+    def __init__(self, arena, world_size: int, bucket_bytes: int = 64 << 20, group=None):
+        self.arena, self.world_size, self.group = arena, world_size, group
+        n = max(1, bucket_bytes // 4)
+        total = arena.total
+        self.buckets: List[Tuple[int, int]] = []
+        end = total
+        while end > 0:
+            start = max(0, end - n)
+            self.buckets.append((start, end))
+            end = start
+        self.enabled = True
+        self._next = 0
+        self._works = []
+
+    def broadcast_params(self, src: int = 0):
+        """DDP constructor semantics (C1): every rank starts from rank 0's parameters."""
+        if self.world_size > 1:
+            dist.broadcast(self.arena.p, src=src, group=self.group)
+
+    def begin(self):
+        self._next = 0
+        self._works = []
+
+    def _fire_until(self, offset: int):
+        if not self.enabled or self.world_size == 1:
+            return
+        g = self.arena.g
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
+            s, e = self.buckets[self._next]
+            self._works.append(dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._next += 1
+
+    def on_ready(self, name: str):
+        self._fire_until(self.arena.entries[name].offset)
+
+    def finish(self):
+        self._fire_until(0)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def grad_divisor(self) -> float:
+        return float(self.world_size) if (self.enabled and self.world_size > 1) else 1.0

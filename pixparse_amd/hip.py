@@ -1,0 +1,90 @@
+"""ctypes binding of libcruller_hip.so (include/crl.h) -- the only way compute reaches the GPU.
+
+There is deliberately NO fallback: if the library is missing or a call fails this module raises.
+The reference-side equivalent of this file is shown in INTEGRATION.md.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcruller_hip.so')
+
+P, I, L, F, Z = c_void_p, c_int, c_int64, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/crl.h one to one
+SIGNATURES = {
+    'crl_version': (I, []),
+    'crl_last_error': (c_char_p, []),
+    'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, P]),
+    'crl_colsum_ws_bytes': (Z, [L]),
+    'crl_colsum_bf16': (I, [P, L, L, L, P, I, P, P]),
+    'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),
+    'crl_layernorm_bwd_ws_bytes': (Z, [L]),
+    'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, I, P, P]),
+    'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, P]),
+    'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
+                         I, I, I, I, F, I, P]),
+    'crl_swin_attn_fwd': (I, [P, P, P, I, I, I, I, I, I, F, P]),
+    'crl_swin_attn_bwd': (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
+    'crl_patch_merge_fwd': (I, [P, P, I, I, I, I, P]),
+    'crl_patch_merge_bwd': (I, [P, P, I, I, I, I, P]),
+    'crl_im2row': (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    'crl_vit_tokens_fwd': (I, [P, P, P, P, I, I, I, P]),
+    'crl_vit_tokens_bwd': (I, [P, P, P, P, I, I, I, I, P]),
+    'crl_embed_fwd': (I, [P, P, P, P, I, I, I, I, P]),
+    'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, P]),
+    'crl_cross_entropy': (I, [P, L, P, L, I, F, F, P, P, P, P, P]),
+    'crl_grad_norm_ws_bytes': (Z, []),
+    'crl_grad_norm': (I, [P, L, F, F, P, P, P]),
+    'crl_adamw': (I, [P, P, P, P, P, L, F, F, F, F, F, I, P, I, P]),
+    'crl_cast_bf16': (I, [P, P, L, P]),
+    'crl_cast_pad_bf16': (I, [P, P, L, L, L, P]),
+    'crl_add_bf16_to_f32': (I, [P, P, L, I, P]),
+}
+
+NT, NN, TN = 0, 1, 2
+EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC = range(6)
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load(path: str = None) -> ctypes.CDLL:
+    """dlopen the library and bind every symbol crl.h declares; raises if any is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            f'{path} not found: build it with `python -m pixparse_amd.build` (hipcc --offload-arch=gfx950). '
+            'pixparse_amd has no CPU or PyTorch fallback path.')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f'{path} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().crl_last_error().decode()
+
+
+def call(name: str, *args) -> None:
+    """invoke an int-returning entry point; non-zero return -> HipLibraryError(crl_last_error())."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise HipLibraryError(f'{name} failed ({rc}): {last_error()}')
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))

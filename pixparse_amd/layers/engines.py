@@ -1,0 +1,547 @@
+"""Explicit forward / backward engines of the Cruller model over the HIP C-ABI.
+
+No autograd, no tracing: every layer's forward stores exactly the activations its hand-written
+backward needs in named device buffers, and the backward sweep runs the dgrad / wgrad / LayerNorm /
+attention kernels in reverse order, accumulating weight gradients straight into the flat fp32
+gradient arena.  Dtype flow = CUDA autocast(bf16) policy: the residual stream
+and LayerNorm statistics are fp32, every GEMM / attention operand and result is bf16 with fp32
+accumulation.
+
+Arithmetic restated (reference call sites):
+  ViT / CLIP-ViT  timm VisionTransformer built at  models/image_encoder_timm.py:13-20
+  Swin            timm SwinTransformer (same call site; output flattened to [B, HW, C])
+  BART decoder    transformers BartForCausalLM built at  models/text_decoder_hf.py:13-33
+  loss            nn.CrossEntropyLoss(ignore_index=-100)  task/task_cruller_pretrain.py:118,251-256
+"""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import BF16, F32, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC
+from .arena import ParamArena
+
+
+class Buffers:
+    """named device buffers, allocated on first use and reused every step (static activation plan)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        t = self.t.get(name)
+        if t is None or t.shape != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.t[name] = t
+        return t
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+class _Base:
+    def __init__(self, arena: ParamArena, prefix: str, bufs: Buffers, tag: str):
+        self.arena, self.prefix, self.bufs, self.tag = arena, prefix, bufs, tag
+
+    def P(self, n):
+        return self.arena.param(self.prefix + n)
+
+    def G(self, n):
+        return self.arena.grad(self.prefix + n)
+
+    def W(self, n):
+        return self.arena.shadow(self.prefix + n)
+
+    def buf(self, name, shape, dtype, zero=False):
+        return self.bufs.get(self.tag + '.' + name, shape, dtype, zero)
+
+    def has(self, n):
+        return (self.prefix + n) in self.arena.entries
+
+    # LN helpers -----------------------------------------------------------------
+    def ln_fwd(self, name, x, key, eps, want_f32=False, want_bf16=True):
+        M, D = x.shape
+        mean = self.buf(key + '.mean', (M,), F32)
+        rstd = self.buf(key + '.rstd', (M,), F32)
+        y32 = self.buf(key + '.y32', (M, D), F32) if want_f32 else None
+        y16 = self.buf(key + '.y16', (M, D), BF16) if want_bf16 else None
+        ops.layernorm_fwd(x, self.P(name + '.weight'), self.P(name + '.bias'), eps, y32, y16, mean, rstd)
+        return y32, y16
+
+    def ln_bwd(self, name, key, x, dy_f32, dy_bf16, dx_f32, acc, dx_bf16):
+        M = x.shape[0]
+        ops.layernorm_bwd(dy_f32, dy_bf16, x, self.P(name + '.weight'), self.bufs.t[self.tag + '.' + key + '.mean'],
+                          self.bufs.t[self.tag + '.' + key + '.rstd'], dx_f32, acc, dx_bf16,
+                          self.G(name + '.weight'), self.G(name + '.bias'), True)
+
+    # Linear backward: wgrad + bias grad (dgrad is issued by the caller: its epilogue differs)
+    def lin_wgrad(self, name, dy, x, has_bias=True, n=None, k=None):
+        gw = self.G(name + '.weight')
+        gw2 = gw.view(gw.shape[0], -1)
+        ops.linear_wgrad(dy, x, gw2, True, n=n, k=k)
+        if has_bias:
+            ops.colsum(dy, self.G(name + '.bias'), True, n=n)
+
+
+# ============================================================================================ ViT
+class ViTEngine(_Base):
+    def __init__(self, arch: dict, in_chans: int, img_size: Tuple[int, int], arena, prefix, bufs):
+        super().__init__(arena, prefix, bufs, 'vit')
+        self.a = arch
+        self.C = in_chans
+        self.H, self.Wd = img_size
+        self.P_ = arch['patch']
+        self.gh, self.gw = self.H // self.P_, self.Wd // self.P_
+        self.Np = self.gh * self.gw
+        self.N = self.Np + 1
+        self.D = arch['dim']
+        self.heads = arch['heads']
+        self.F = self.D * arch['mlp_ratio']
+        self.Kreal = in_chans * self.P_ * self.P_
+        self.Kp = ops.round_up(self.Kreal, ops.K_PAD)
+        self.pe_shadow = None  # [D, Kp] bf16 padded copy of the patch-embed weight
+
+    @staticmethod
+    def param_shapes(arch, in_chans, img_size):
+        P, D = arch['patch'], arch['dim']
+        gh, gw = img_size[0] // P, img_size[1] // P
+        F_ = D * arch['mlp_ratio']
+        s = [('cls_token', (1, 1, D)), ('pos_embed', (1, gh * gw + 1, D)), ('patch_embed.proj.weight', (D, in_chans, P, P))]
+        if not arch['pre_norm']:
+            s.append(('patch_embed.proj.bias', (D,)))
+        else:
+            s += [('norm_pre.weight', (D,)), ('norm_pre.bias', (D,))]
+        for i in range(arch['depth']):
+            bp = f'blocks.{i}.'
+            s += [(bp + 'norm1.weight', (D,)), (bp + 'norm1.bias', (D,)),
+                  (bp + 'attn.qkv.weight', (3 * D, D)), (bp + 'attn.qkv.bias', (3 * D,)),
+                  (bp + 'attn.proj.weight', (D, D)), (bp + 'attn.proj.bias', (D,)),
+                  (bp + 'norm2.weight', (D,)), (bp + 'norm2.bias', (D,)),
+                  (bp + 'mlp.fc1.weight', (F_, D)), (bp + 'mlp.fc1.bias', (F_,)),
+                  (bp + 'mlp.fc2.weight', (D, F_)), (bp + 'mlp.fc2.bias', (D,))]
+        s += [('norm.weight', (D,)), ('norm.bias', (D,))]
+        return s
+
+    def out_tokens(self):
+        return self.N
+
+    def refresh_shadows(self):
+        """padded bf16 copy of the conv weight as a [D, Kp] GEMM operand (K = C*P*P is not a multiple of 32)."""
+        if self.pe_shadow is None:
+            self.pe_shadow = torch.zeros(self.D, self.Kp, dtype=BF16, device=self.bufs.device)
+        w = self.P('patch_embed.proj.weight')
+        ops.cast_pad_bf16(w, self.pe_shadow, self.D, self.Kreal, self.Kp)
+
+    def forward(self, image: torch.Tensor):
+        a, B, D, N, F_ = self.a, image.shape[0], self.D, self.N, self.F
+        M = B * N
+        self.B = B
+        eps = a['ln_eps']
+        patches = self.buf('patches', (B * self.Np, self.Kp), BF16)
+        ops.im2row(image, patches, self.P_, self.gh, self.gw)
+        pe = self.buf('pe', (B * self.Np, D), BF16)
+        ops.linear_fwd(patches, self.pe_shadow, None if a['pre_norm'] else self.P('patch_embed.proj.bias'), pe)
+        x = self.buf('x0', (M, D), F32)
+        ops.vit_tokens_fwd(pe, self.P('cls_token'), self.P('pos_embed'), x, B, self.Np, D)
+        if a['pre_norm']:
+            x, _ = self.ln_fwd('norm_pre', x, 'norm_pre', eps, want_f32=True, want_bf16=False)
+        scale = (D // self.heads) ** -0.5
+        for i in range(a['depth']):
+            bp, k = f'blocks.{i}.', f'b{i}'
+            _, h1 = self.ln_fwd(bp + 'norm1', x, k + '.ln1', eps)
+            qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
+            ops.linear_fwd(h1, self.W(bp + 'attn.qkv.weight'), self.P(bp + 'attn.qkv.bias'), qkv)
+            q3 = qkv.view(B, N, 3 * D)
+            o = self.buf(k + '.o', (M, D), BF16)
+            lse = self.buf(k + '.lse', (B, self.heads, N), F32)
+            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:3 * D], o.view(B, N, D), lse, self.heads, scale, False)
+            x2 = self.buf(k + '.x2', (M, D), F32)
+            ops.linear_fwd(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, EPI_F32_RESID, resid=x)
+            _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
+            pre = self.buf(k + '.pre', (M, F_), BF16)
+            act = self.buf(k + '.act', (M, F_), BF16)
+            ops.linear_fwd(h2, self.W(bp + 'mlp.fc1.weight'), self.P(bp + 'mlp.fc1.bias'), act, EPI_BF16_GELU, aux=pre)
+            x3 = self.buf(k + '.x3', (M, D), F32)
+            ops.linear_fwd(act, self.W(bp + 'mlp.fc2.weight'), self.P(bp + 'mlp.fc2.bias'), x3, EPI_F32_RESID, resid=x2)
+            self._save_in(k, x)
+            x = x3
+        self.x_last = x
+        enc32, enc16 = self.ln_fwd('norm', x, 'norm', eps, want_f32=True, want_bf16=True)
+        return enc32, enc16
+
+    def _save_in(self, k, x):
+        self.bufs.t[self.tag + '.' + k + '.xin'] = x  # alias: block input is the previous block's x3 / x0 / norm_pre out
+
+    def backward(self, denc: torch.Tensor, on_layer_done: Optional[Callable[[str], None]] = None):
+        """denc: fp32 [B*N, D] gradient of the encoder output."""
+        a, B, D, N, F_ = self.a, self.B, self.D, self.N, self.F
+        M = B * N
+        T = self.bufs.t
+        tg = self.tag + '.'
+        dx = self.buf('dx', (M, D), F32)
+        gb = self.buf('gb', (M, D), BF16)
+        self.ln_bwd('norm', 'norm', self.x_last, denc, None, dx, False, gb)
+        if on_layer_done:
+            on_layer_done(self.prefix + 'norm.weight')
+        scale = (D // self.heads) ** -0.5
+        dpre = self.buf('dpre', (M, F_), BF16)
+        dh = self.buf('dh', (M, D), BF16)
+        do = self.buf('do', (M, D), BF16)
+        dqkv = self.buf('dqkv', (M, 3 * D), BF16)
+        delta = self.buf('delta', (B, self.heads, N), F32)
+        for i in reversed(range(a['depth'])):
+            bp, k = f'blocks.{i}.', f'b{i}'
+            xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
+            h1, h2 = T[tg + k + '.ln1.y16'], T[tg + k + '.ln2.y16']
+            qkv, o, lse = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.lse']
+            pre, act = T[tg + k + '.pre'], T[tg + k + '.act']
+            # ---- MLP: x3 = x2 + fc2(gelu(fc1(LN2(x2))));  gb = bf16(dx3)
+            ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
+            self.lin_wgrad(bp + 'mlp.fc2', gb, act)
+            ops.linear_dgrad(dpre, self.W(bp + 'mlp.fc1.weight'), dh)
+            self.lin_wgrad(bp + 'mlp.fc1', dpre, h2)
+            self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb)     # dx := dx2, gb := bf16(dx2)
+            # ---- attention: x2 = xin + proj(attn(qkv(LN1(xin))))
+            ops.linear_dgrad(gb, self.W(bp + 'attn.proj.weight'), do)
+            self.lin_wgrad(bp + 'attn.proj', gb, o)
+            q3, dq3 = qkv.view(B, N, 3 * D), dqkv.view(B, N, 3 * D)
+            ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do.view(B, N, D), lse, delta,
+                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], self.heads, scale, False)
+            ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
+            self.lin_wgrad(bp + 'attn.qkv', dqkv, h1)
+            self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb)    # dx := d(xin)
+            if on_layer_done:
+                on_layer_done(self.prefix + bp + 'norm1.weight')
+        if a['pre_norm']:
+            self.ln_bwd('norm_pre', 'norm_pre', T[tg + 'x0'], dx, None, dx, False, None)
+        dpe = T[tg + 'pe']
+        ops.vit_tokens_bwd(dx, dpe, self.G('cls_token'), self.G('pos_embed'), B, self.Np, D, True)
+        self.lin_wgrad('patch_embed.proj', dpe, T[tg + 'patches'], has_bias=not a['pre_norm'], k=self.Kreal)
+        if on_layer_done:
+            on_layer_done(self.prefix + 'cls_token')
+
+
+# ============================================================================================ Swin
+class SwinEngine(_Base):
+    def __init__(self, arch: dict, in_chans: int, img_size: Tuple[int, int], arena, prefix, bufs):
+        super().__init__(arena, prefix, bufs, 'swin')
+        self.a, self.C_in = arch, in_chans
+        self.H, self.Wd = img_size
+        self.geo = self.stage_geometry(arch, img_size)
+        self.P_ = arch['patch']
+        self.Kreal = in_chans * self.P_ * self.P_
+        self.Kp = ops.round_up(self.Kreal, ops.K_PAD)
+        self.pe_shadow = None
+
+    @staticmethod
+    def stage_geometry(arch, img_size):
+        Hf, Wf = img_size[0] // arch['patch'], img_size[1] // arch['patch']
+        out = []
+        for si, depth in enumerate(arch['depths']):
+            if si > 0:
+                Hf, Wf = Hf // 2, Wf // 2
+            C = arch['embed_dim'] * (2 ** si)
+            w = arch['window']
+            if min(Hf, Wf) <= w:
+                w = min(Hf, Wf)
+            out.append((Hf, Wf, C, arch['heads'][si], w, depth))
+        return out
+
+    @staticmethod
+    def param_shapes(arch, in_chans, img_size):
+        P, C0 = arch['patch'], arch['embed_dim']
+        s = [('patch_embed.proj.weight', (C0, in_chans, P, P)), ('patch_embed.proj.bias', (C0,)),
+             ('patch_embed.norm.weight', (C0,)), ('patch_embed.norm.bias', (C0,))]
+        for si, (Hf, Wf, C, heads, w, depth) in enumerate(SwinEngine.stage_geometry(arch, img_size)):
+            sp = f'layers.{si}.'
+            if si > 0:
+                s += [(sp + 'downsample.norm.weight', (2 * C,)), (sp + 'downsample.norm.bias', (2 * C,)),
+                      (sp + 'downsample.reduction.weight', (C, 2 * C))]
+            F_ = C * arch['mlp_ratio']
+            for bi in range(depth):
+                bp = sp + f'blocks.{bi}.'
+                s += [(bp + 'norm1.weight', (C,)), (bp + 'norm1.bias', (C,)),
+                      (bp + 'attn.qkv.weight', (3 * C, C)), (bp + 'attn.qkv.bias', (3 * C,)),
+                      (bp + 'attn.relative_position_bias_table', ((2 * w - 1) ** 2, heads)),
+                      (bp + 'attn.proj.weight', (C, C)), (bp + 'attn.proj.bias', (C,)),
+                      (bp + 'norm2.weight', (C,)), (bp + 'norm2.bias', (C,)),
+                      (bp + 'mlp.fc1.weight', (F_, C)), (bp + 'mlp.fc1.bias', (F_,)),
+                      (bp + 'mlp.fc2.weight', (C, F_)), (bp + 'mlp.fc2.bias', (C,))]
+        Cl = C0 * 2 ** (len(arch['depths']) - 1)
+        s += [('norm.weight', (Cl,)), ('norm.bias', (Cl,))]
+        return s
+
+    def out_tokens(self):
+        Hf, Wf = self.geo[-1][0], self.geo[-1][1]
+        return Hf * Wf
+
+    def refresh_shadows(self):
+        C0 = self.a['embed_dim']
+        if self.pe_shadow is None:
+            self.pe_shadow = torch.zeros(C0, self.Kp, dtype=BF16, device=self.bufs.device)
+        ops.cast_pad_bf16(self.P('patch_embed.proj.weight'), self.pe_shadow, C0, self.Kreal, self.Kp)
+
+    def forward(self, image):
+        a, B = self.a, image.shape[0]
+        self.B = B
+        eps = a['ln_eps']
+        Hf0, Wf0, C0 = self.geo[0][0], self.geo[0][1], self.geo[0][2]
+        patches = self.buf('patches', (B * Hf0 * Wf0, self.Kp), BF16)
+        ops.im2row(image, patches, self.P_, Hf0, Wf0)
+        pe = self.buf('pe', (B * Hf0 * Wf0, C0), BF16)
+        ops.linear_fwd(patches, self.pe_shadow, self.P('patch_embed.proj.bias'), pe)
+        pe32 = self.buf('pe32', (B * Hf0 * Wf0, C0), F32)
+        ops.add_bf16_to_f32(pe, pe32, False)
+        x, _ = self.ln_fwd('patch_embed.norm', pe32, 'pe_norm', eps, want_f32=True, want_bf16=False)
+        for si, (Hf, Wf, C, heads, w, depth) in enumerate(self.geo):
+            sp, M = f'layers.{si}.', B * Hf * Wf
+            if si > 0:
+                Cp = C // 2
+                mg = self.buf(f's{si}.merged', (M, 4 * Cp), F32)
+                ops.patch_merge_fwd(x, mg, B, Hf * 2, Wf * 2, Cp)
+                _, mh = self.ln_fwd(sp + 'downsample.norm', mg, f's{si}.dsn', eps)
+                red = self.buf(f's{si}.red', (M, C), BF16)
+                ops.linear_fwd(mh, self.W(sp + 'downsample.reduction.weight'), None, red)
+                x = self.buf(f's{si}.x', (M, C), F32)
+                ops.add_bf16_to_f32(red, x, False)
+            F_ = C * a['mlp_ratio']
+            scale = (C // heads) ** -0.5
+            for bi in range(depth):
+                bp, k = sp + f'blocks.{bi}.', f's{si}b{bi}'
+                shift = 0 if (bi % 2 == 0 or w >= min(Hf, Wf)) else w // 2
+                _, h1 = self.ln_fwd(bp + 'norm1', x, k + '.ln1', eps)
+                qkv = self.buf(k + '.qkv', (M, 3 * C), BF16)
+                ops.linear_fwd(h1, self.W(bp + 'attn.qkv.weight'), self.P(bp + 'attn.qkv.bias'), qkv)
+                o = self.buf(k + '.o', (M, C), BF16)
+                ops.swin_attn_fwd(qkv, self.P(bp + 'attn.relative_position_bias_table'), o, B, Hf, Wf, heads, w, shift, scale)
+                x2 = self.buf(k + '.x2', (M, C), F32)
+                ops.linear_fwd(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, EPI_F32_RESID, resid=x)
+                _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
+                pre = self.buf(k + '.pre', (M, F_), BF16)
+                act = self.buf(k + '.act', (M, F_), BF16)
+                ops.linear_fwd(h2, self.W(bp + 'mlp.fc1.weight'), self.P(bp + 'mlp.fc1.bias'), act, EPI_BF16_GELU, aux=pre)
+                x3 = self.buf(k + '.x3', (M, C), F32)
+                ops.linear_fwd(act, self.W(bp + 'mlp.fc2.weight'), self.P(bp + 'mlp.fc2.bias'), x3, EPI_F32_RESID, resid=x2)
+                self.bufs.t[self.tag + '.' + k + '.xin'] = x
+                x = x3
+        self.x_last = x
+        return self.ln_fwd('norm', x, 'norm', eps, want_f32=True, want_bf16=True)
+
+    def backward(self, denc, on_layer_done=None):
+        a, B, T, tg = self.a, self.B, self.bufs.t, self.tag + '.'
+        Hl, Wl, Cl = self.geo[-1][0], self.geo[-1][1], self.geo[-1][2]
+        dx = self.buf(f'dx{len(self.geo) - 1}', (B * Hl * Wl, Cl), F32)
+        gb = self.buf(f'gb{len(self.geo) - 1}', (B * Hl * Wl, Cl), BF16)
+        self.ln_bwd('norm', 'norm', self.x_last, denc, None, dx, False, gb)
+        if on_layer_done:
+            on_layer_done(self.prefix + 'norm.weight')
+        for si in reversed(range(len(self.geo))):
+            Hf, Wf, C, heads, w, depth = self.geo[si]
+            sp, M = f'layers.{si}.', B * Hf * Wf
+            F_ = C * a['mlp_ratio']
+            scale = (C // heads) ** -0.5
+            dpre = self.buf(f'dpre{si}', (M, F_), BF16)
+            dh = self.buf(f'dh{si}', (M, C), BF16)
+            do = self.buf(f'do{si}', (M, C), BF16)
+            dqkv = self.buf(f'dqkv{si}', (M, 3 * C), BF16)
+            for bi in reversed(range(depth)):
+                bp, k = sp + f'blocks.{bi}.', f's{si}b{bi}'
+                shift = 0 if (bi % 2 == 0 or w >= min(Hf, Wf)) else w // 2
+                xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
+                h1, h2 = T[tg + k + '.ln1.y16'], T[tg + k + '.ln2.y16']
+                qkv, o, pre, act = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.pre'], T[tg + k + '.act']
+                ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
+                self.lin_wgrad(bp + 'mlp.fc2', gb, act)
+                ops.linear_dgrad(dpre, self.W(bp + 'mlp.fc1.weight'), dh)
+                self.lin_wgrad(bp + 'mlp.fc1', dpre, h2)
+                self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb)
+                ops.linear_dgrad(gb, self.W(bp + 'attn.proj.weight'), do)
+                self.lin_wgrad(bp + 'attn.proj', gb, o)
+                ops.swin_attn_bwd(qkv, self.P(bp + 'attn.relative_position_bias_table'), do, dqkv,
+                                  self.G(bp + 'attn.relative_position_bias_table'), B, Hf, Wf, heads, w, shift, scale)
+                ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
+                self.lin_wgrad(bp + 'attn.qkv', dqkv, h1)
+                self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb)
+                if on_layer_done:
+                    on_layer_done(self.prefix + bp + 'norm1.weight')
+            if si > 0:
+                # x_stage = float(reduction(LN(merge(x_prev))))  -> gb is bf16(dx) = d(reduction out)
+                Cp = C // 2
+                mh, mg = T[tg + f's{si}.dsn.y16'], T[tg + f's{si}.merged']
+                dmh = self.buf(f'dmh{si}', (M, 4 * Cp), BF16)
+                ops.linear_dgrad(gb, self.W(sp + 'downsample.reduction.weight'), dmh)
+                self.lin_wgrad(sp + 'downsample.reduction', gb, mh, has_bias=False)
+                dmg = self.buf(f'dmg{si}', (M, 4 * Cp), F32)
+                self.ln_bwd(sp + 'downsample.norm', f's{si}.dsn', mg, None, dmh, dmg, False, None)
+                dx = self.buf(f'dx{si - 1}', (B * Hf * 2 * Wf * 2, Cp), F32)
+                gb = self.buf(f'gb{si - 1}', (B * Hf * 2 * Wf * 2, Cp), BF16)
+                ops.patch_merge_bwd(dmg, dx, B, Hf * 2, Wf * 2, Cp)
+                ops.cast_bf16(dx, gb)
+                if on_layer_done:
+                    on_layer_done(self.prefix + sp + 'downsample.norm.weight')
+        # patch embed: x = LN(float(conv(img)))
+        Hf0, Wf0, C0 = self.geo[0][0], self.geo[0][1], self.geo[0][2]
+        dpe32 = self.buf('dpe32', (B * Hf0 * Wf0, C0), F32)
+        dpe = self.buf('dpe', (B * Hf0 * Wf0, C0), BF16)
+        self.ln_bwd('patch_embed.norm', 'pe_norm', T[tg + 'pe32'], dx, None, dpe32, False, dpe)
+        self.lin_wgrad('patch_embed.proj', dpe, T[tg + 'patches'], has_bias=True, k=self.Kreal)
+        if on_layer_done:
+            on_layer_done(self.prefix + 'patch_embed.proj.weight')
+
+
+# ============================================================================================ BART decoder
+class BartEngine(_Base):
+    DP = 'model.decoder.'
+
+    def __init__(self, arch: dict, n_layers: int, vocab: int, max_pos: int, arena, prefix, bufs):
+        super().__init__(arena, prefix, bufs, 'dec')
+        self.a, self.L, self.V, self.max_pos = arch, n_layers, vocab, max_pos
+        self.Vp = ops.round_up(vocab, ops.VOCAB_PAD)
+        self.D, self.heads, self.F = arch['d_model'], arch['heads'], arch['ffn']
+
+    @staticmethod
+    def param_shapes(arch, n_layers, vocab, max_pos):
+        """arena order: embeddings first, then per layer [self q,k,v] [out] LN [cross q] [cross k,v] [out] LN fc1 fc2 LN
+        (q/k/v and k/v stay adjacent so one fused GEMM covers them)."""
+        D, F_ = arch['d_model'], arch['ffn']
+        assert D % 64 == 0, 'd_model must be a multiple of 64 (fused q/k/v arena views, head_dim 64)'
+        dp = BartEngine.DP
+        Vp = ops.round_up(vocab, ops.VOCAB_PAD)
+        s = [(dp + 'embed_tokens.weight', (vocab, D), Vp * D), (dp + 'embed_positions.weight', (max_pos + 2, D)),
+             (dp + 'layernorm_embedding.weight', (D,)), (dp + 'layernorm_embedding.bias', (D,))]
+        for i in range(n_layers):
+            lp = dp + f'layers.{i}.'
+            for a in ('self_attn', 'encoder_attn'):
+                for proj in ('q_proj', 'k_proj', 'v_proj'):
+                    s.append((lp + f'{a}.{proj}.weight', (D, D)))
+                for proj in ('q_proj', 'k_proj', 'v_proj'):
+                    s.append((lp + f'{a}.{proj}.bias', (D,)))
+                s += [(lp + f'{a}.out_proj.weight', (D, D)), (lp + f'{a}.out_proj.bias', (D,)),
+                      (lp + f'{a}_layer_norm.weight', (D,)), (lp + f'{a}_layer_norm.bias', (D,))]
+            s += [(lp + 'fc1.weight', (F_, D)), (lp + 'fc1.bias', (F_,)), (lp + 'fc2.weight', (D, F_)), (lp + 'fc2.bias', (D,)),
+                  (lp + 'final_layer_norm.weight', (D,)), (lp + 'final_layer_norm.bias', (D,))]
+        return s
+
+    # fused views: q,k,v (or k,v) weights/biases are adjacent ALIGN-padded entries of equal size ------------------
+    def _fused(self, kind, first, count, rows):
+        e = self.arena.entries[self.prefix + first]
+        flat = {'p': self.arena.p, 'g': self.arena.g, 'w': self.arena.pb}[kind]
+        return flat[e.offset:e.offset + count * e.numel].view(*rows)
+
+    def fw(self, kind, lp, attn, first, count):   # fused weight [count*D, D]
+        return self._fused(kind, lp + f'{attn}.{first}.weight', count, (count * self.D, self.D))
+
+    def fb(self, kind, lp, attn, first, count):   # fused bias [count*D]
+        return self._fused(kind, lp + f'{attn}.{first}.bias', count, (count * self.D,))
+
+    def forward(self, ids: torch.Tensor, enc16: torch.Tensor, S: int):
+        """ids [B, T] int64; enc16 bf16 [B*S, D] -> logits buffer bf16 [B*T, Vp]."""
+        dp, D, F_, H = self.DP, self.D, self.F, self.heads
+        B, T = ids.shape
+        self.B, self.T, self.S, self.ids = B, T, S, ids
+        M, Me = B * T, B * S
+        eps = self.a['ln_eps']
+        scale = (D // H) ** -0.5
+        emb = self.buf('emb', (M, D), F32)
+        ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2)
+        h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'ln_emb', eps, want_f32=True, want_bf16=True)
+        for i in range(self.L):
+            lp, k = dp + f'layers.{i}.', f'l{i}'
+            qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
+            ops.linear_fwd(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), qkv)
+            q3 = qkv.view(B, T, 3 * D)
+            o1 = self.buf(k + '.o1', (M, D), BF16)
+            lse1 = self.buf(k + '.lse1', (B, H, T), F32)
+            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True)
+            t1 = self.buf(k + '.t1', (M, D), F32)
+            ops.linear_fwd(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
+            h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
+            q2 = self.buf(k + '.q2', (M, D), BF16)
+            ops.linear_fwd(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
+            kv2 = self.buf(k + '.kv2', (Me, 2 * D), BF16)
+            ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
+            kv3 = kv2.view(B, S, 2 * D)
+            o2 = self.buf(k + '.o2', (M, D), BF16)
+            lse2 = self.buf(k + '.lse2', (B, H, T), F32)
+            ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False)
+            t2 = self.buf(k + '.t2', (M, D), F32)
+            ops.linear_fwd(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
+            h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
+            pre = self.buf(k + '.pre', (M, F_), BF16)
+            act = self.buf(k + '.act', (M, F_), BF16)
+            ops.linear_fwd(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU, aux=pre)
+            t3 = self.buf(k + '.t3', (M, D), F32)
+            ops.linear_fwd(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, EPI_F32_RESID, resid=h2)
+            self.bufs.t[self.tag + '.' + k + '.hb'] = hb
+            h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, k + '.ln3', eps, True, True)
+        self.h_last16 = hb
+        logits = self.buf('logits', (M, self.Vp), BF16)
+        ops.linear_fwd(hb, self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D), None, logits)
+        return logits
+
+    def backward(self, dlogits: torch.Tensor, enc16: torch.Tensor, denc: torch.Tensor, on_layer_done=None):
+        """dlogits bf16 [M, Vp] (pad columns zero); accumulates the encoder-output gradient into denc (fp32 [B*S, D],
+        must be zeroed by the caller)."""
+        dp, D, F_, H = self.DP, self.D, self.F, self.heads
+        B, T, S = self.B, self.T, self.S
+        M, Me = B * T, B * S
+        Tb, tg = self.bufs.t, self.tag + '.'
+        scale = (D // H) ** -0.5
+        Ew = self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D)
+        Eg = self.arena.grad(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D)
+        dyb = self.buf('dyb', (M, D), BF16)        # bf16 gradient arriving at a layer output from GEMM consumers
+        ops.linear_dgrad(dlogits, Ew, dyb)
+        ops.linear_wgrad(dlogits, self.h_last16, Eg, True)
+        dy32 = None                                 # fp32 gradient arriving through the residual path
+        dt = self.buf('dt', (M, D), F32)
+        dtb = self.buf('dtb', (M, D), BF16)
+        dt2 = self.buf('dt2', (M, D), F32)
+        dpre = self.buf('dpre', (M, F_), BF16)
+        dhb = self.buf('dhb', (M, D), BF16)
+        do = self.buf('do', (M, D), BF16)
+        dq2 = self.buf('dq2', (M, D), BF16)
+        dkv2 = self.buf('dkv2', (Me, 2 * D), BF16)
+        dqkv = self.buf('dqkv', (M, 3 * D), BF16)
+        delta = self.buf('delta', (B, H, T), F32)
+        for i in reversed(range(self.L)):
+            lp, k = dp + f'layers.{i}.', f'l{i}'
+            g = lambda n: Tb[tg + k + n]
+            # ---- h_out = LN3(t3), t3 = h2 + fc2(gelu(fc1(h2b)))
+            self.ln_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, False, dtb)
+            ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.pre'))
+            self.lin_wgrad(lp + 'fc2', dtb, g('.act'))
+            ops.linear_dgrad(dpre, self.W(lp + 'fc1.weight'), dhb)
+            self.lin_wgrad(lp + 'fc1', dpre, g('.ln2.y16'))
+            # ---- h2 = LN2(t2), t2 = h1 + out_c(attn(q_c(h1b), kv_c(enc)))
+            self.ln_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, False, dtb)
+            ops.linear_dgrad(dtb, self.W(lp + 'encoder_attn.out_proj.weight'), do)
+            self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'))
+            kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
+            ops.attn_bwd(g('.q2').view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], g('.o2').view(B, T, D), do.view(B, T, D), g('.lse2'), delta,
+                         dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False)
+            ops.linear_dgrad(dq2, self.W(lp + 'encoder_attn.q_proj.weight'), dhb)
+            self.lin_wgrad(lp + 'encoder_attn.q_proj', dq2, g('.ln1.y16'))
+            ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32_ACC)
+            ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
+            ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
+            # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
+            self.ln_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, False, dtb)
+            ops.linear_dgrad(dtb, self.W(lp + 'self_attn.out_proj.weight'), do)
+            self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'))
+            q3, dq3 = g('.qkv').view(B, T, 3 * D), dqkv.view(B, T, 3 * D)
+            ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
+                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True)
+            ops.linear_dgrad(dqkv, self.fw('w', lp, 'self_attn', 'q_proj', 3), dyb)
+            ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True)
+            ops.colsum(dqkv, self.fb('g', lp, 'self_attn', 'q_proj', 3), True)
+            dy32 = dt  # residual-path gradient for the layer below (dt now holds d t1)
+            if on_layer_done:
+                on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')
+        # ---- h0 = LN(emb)
+        demb = self.buf('demb', (M, D), F32)
+        self.ln_bwd(dp + 'layernorm_embedding', 'ln_emb', Tb[tg + 'emb'], dy32, dyb, demb, False, None)
+        ops.embed_bwd(self.ids, demb, self.G(dp + 'embed_tokens.weight'), self.G(dp + 'embed_positions.weight'), 2, True)
+        if on_layer_done:
+            on_layer_done(self.prefix + dp + 'embed_tokens.weight')

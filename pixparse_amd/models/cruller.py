@@ -1,0 +1,252 @@
+"""Cruller = image encoder + BART text decoder (ref: models/cruller.py:8-21), MI355X-native.
+
+Same surface as the reference module -- ``Cruller(cfg)``, ``.image_encoder.trunk`` (with
+``pretrained_cfg``), ``.text_decoder.trunk.resize_token_embeddings(n)``,
+``forward(image_input, text_input)['logits']``, ``state_dict()`` with the timm / HF key names --
+but the parameters are views into one flat fp32 arena and all arithmetic is the explicit
+forward/backward engine over libcruller_hip.so (layers/engines.py).  There is no CPU path:
+calling forward on a CPU-resident model raises.
+"""
+from collections import OrderedDict
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers.arena import ParamArena
+from ..layers.engines import BartEngine, Buffers, SwinEngine, ViTEngine
+from .archs import BART_ARCHS, SWIN_ARCHS, VIT_ARCHS
+from .config import ModelCfg
+
+ENC_PREFIX = 'image_encoder.trunk.'
+DEC_PREFIX = 'text_decoder.trunk.'
+
+
+class _Container(nn.Module):
+    """bare module used to reproduce the reference's state_dict key hierarchy"""
+
+
+class _DecoderTrunk(_Container):
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, '_owner', owner)
+
+    def resize_token_embeddings(self, new_num_tokens: int):
+        self._owner._resize_vocab(int(new_num_tokens))
+        return self.model.decoder.embed_tokens
+
+
+class _TextDecoder(_Container):
+    def prepare_inputs_for_inference(self, input_ids, encoder_outputs, pad_token_id, past_key_values=None, past=None,
+                                     use_cache=None, attention_mask=None):
+        """ref: models/text_decoder_hf.py:47-78"""
+        if past is not None:
+            past_key_values = past
+        attention_mask = input_ids.ne(pad_token_id).long()
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        return {'input_ids': input_ids, 'attention_mask': attention_mask, 'past_key_values': past_key_values,
+                'use_cache': use_cache, 'encoder_hidden_states': encoder_outputs}
+
+
+class CausalLMOutput(dict):
+    """mapping with attribute access, like transformers' ModelOutput (train_step indexes ['logits'],
+    utils/ocr_utils.py reads .logits)"""
+    __getattr__ = dict.get
+
+
+def _set_param(root: nn.Module, dotted: str, p: nn.Parameter, factories=None):
+    parts = dotted.split('.')
+    mod = root
+    for i, name in enumerate(parts[:-1]):
+        nxt = mod._modules.get(name)
+        if nxt is None:
+            nxt = _Container()
+            mod.add_module(name, nxt)
+        mod = nxt
+    mod.register_parameter(parts[-1], p)
+
+
+class Cruller(nn.Module):
+    def __init__(self, cfg: ModelCfg, vocab_size: Optional[int] = None):
+        super().__init__()
+        self.cfg = cfg
+        ie, td = cfg.image_encoder, cfg.text_decoder
+        assert ie.name, 'image encoder name required'            # image_encoder_timm.py:8
+        assert ie.image_fmt in ('L', 'RGB')                       # image_encoder_timm.py:12
+        assert td.name, 'text decoder name required'              # text_decoder_hf.py:11
+        if ie.name in SWIN_ARCHS:
+            self.enc_kind, self.enc_arch = 'swin', SWIN_ARCHS[ie.name]
+        elif ie.name in VIT_ARCHS:
+            self.enc_kind, self.enc_arch = 'vit', VIT_ARCHS[ie.name]
+        else:
+            raise ValueError(f'unknown image encoder {ie.name!r}; known: {sorted(VIT_ARCHS) + sorted(SWIN_ARCHS)}')
+        if td.name not in BART_ARCHS:
+            raise ValueError(f'unknown text decoder {td.name!r}; known: {sorted(BART_ARCHS)}')
+        self.dec_arch = BART_ARCHS[td.name]
+        self.in_chans = 1 if ie.image_fmt == 'L' else 3
+        self.img_size = tuple(ie.image_size) if ie.image_size is not None else (224, 224)
+        self.n_layers = td.num_decoder_layers if td.num_decoder_layers is not None else 6
+        self.max_length = td.max_length if td.max_length is not None else 1024
+        self.vocab_size = int(vocab_size or self.dec_arch['vocab'])
+        enc_dim = self.enc_arch['dim'] if self.enc_kind == 'vit' else self.enc_arch['embed_dim'] * 2 ** (len(self.enc_arch['depths']) - 1)
+        assert enc_dim == self.dec_arch['d_model'], f'encoder width {enc_dim} != decoder d_model {self.dec_arch["d_model"]}'
+        self.arena: Optional[ParamArena] = None
+        self._engines = None
+        self._build()
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ structure
+    def _enc_shapes(self):
+        cls = SwinEngine if self.enc_kind == 'swin' else ViTEngine
+        return cls.param_shapes(self.enc_arch, self.in_chans, self.img_size)
+
+    def _build(self):
+        arena = ParamArena()
+        for item in self._enc_shapes():
+            arena.add(ENC_PREFIX + item[0], item[1])
+        for item in BartEngine.param_shapes(self.dec_arch, self.n_layers, self.vocab_size, self.max_length):
+            arena.add(DEC_PREFIX + item[0], item[1], item[2] if len(item) > 2 else None)
+        arena.materialize('cpu')
+        self.arena = arena
+        self._engines = None
+        # module tree mirroring the reference checkpoint keys
+        self._modules.pop('image_encoder', None)
+        self._modules.pop('text_decoder', None)
+        self.image_encoder = _Container()
+        self.image_encoder.trunk = _Container()
+        self.image_encoder.trunk.pretrained_cfg = {'mean': self.enc_arch['mean'], 'std': self.enc_arch['std']}
+        self.text_decoder = _TextDecoder()
+        self.text_decoder.trunk = _DecoderTrunk(self)
+        self._pmap = OrderedDict()
+        for name in arena.entries:
+            p = nn.Parameter(arena.param(name), requires_grad=True)
+            self._pmap[name] = p
+            _set_param(self, name, p)
+        # tied LM head (hf:1224-1234): same Parameter object under both keys
+        self.text_decoder.trunk.add_module('lm_head', _Container())
+        self.text_decoder.trunk.lm_head.register_parameter('weight', self._pmap[DEC_PREFIX + 'model.decoder.embed_tokens.weight'])
+
+    def reset_parameters(self, std: float = 0.02):
+        """timm / HF style random init (pretrained weights cannot be fetched offline): N(0, .02) matrices and
+        embeddings, zero biases, unit LayerNorm scales, zero row for the pad embedding (id 1)."""
+        with torch.no_grad():
+            for name, p in self._pmap.items():
+                if name.endswith('.bias'):
+                    p.zero_()
+                elif 'norm' in name.rsplit('.', 2)[-2] and name.endswith('.weight'):
+                    p.fill_(1.0)
+                elif name.endswith('cls_token'):
+                    p.normal_(0.0, 1e-6)
+                else:
+                    p.normal_(0.0, std)
+            self._pmap[DEC_PREFIX + 'model.decoder.embed_tokens.weight'][1].zero_()
+
+    def _resize_vocab(self, n: int):
+        if n == self.vocab_size:
+            return
+        assert self.arena.p.device.type == 'cpu' and self.arena.g is None, 'resize_token_embeddings must precede train_setup()'
+        old = {k: v.detach().clone() for k, v in self._pmap.items()}
+        old_v = self.vocab_size
+        self.vocab_size = n
+        self._build()
+        key = DEC_PREFIX + 'model.decoder.embed_tokens.weight'
+        with torch.no_grad():
+            for k, p in self._pmap.items():
+                if k != key:
+                    p.copy_(old[k])
+            keep = min(old_v, n)
+            self._pmap[key][:keep].copy_(old[key][:keep])
+            if n > old_v:  # transformers 5 draws new rows around the old embeddings' mean; use the mean + small noise
+                mean = old[key].mean(0, keepdim=True)
+                self._pmap[key][old_v:].copy_(mean + 1e-3 * old[key].std() * torch.randn(n - old_v, mean.shape[1]))
+
+    # ------------------------------------------------------------------ device placement
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self.arena.p.device))
+        if probe.dtype != torch.float32:
+            raise TypeError('Cruller keeps fp32 master parameters; bf16 compute is internal (autocast policy)')
+        self.arena.apply_(fn)
+        for name, p in self._pmap.items():
+            p.data = self.arena.param(name)
+            if p.grad is not None:
+                p.grad = None
+        self._engines = None
+        return self
+
+    @property
+    def device(self):
+        return self.arena.p.device
+
+    # ------------------------------------------------------------------ engines
+    def _ensure_engines(self):
+        if self._engines is not None:
+            return self._engines
+        if self.device.type != 'cuda':
+            raise RuntimeError('Cruller runs only on an MI355X (HIP): move the model to a cuda device; there is no CPU path')
+        from .. import hip
+        hip.load()
+        self.arena.alloc_shadow()
+        bufs = Buffers(self.device)
+        cls = SwinEngine if self.enc_kind == 'swin' else ViTEngine
+        enc = cls(self.enc_arch, self.in_chans, self.img_size, self.arena, ENC_PREFIX, bufs)
+        dec = BartEngine(self.dec_arch, self.n_layers, self.vocab_size, self.max_length, self.arena, DEC_PREFIX, bufs)
+        self._engines = (enc, dec, bufs)
+        self.refresh_shadows()
+        return self._engines
+
+    def refresh_shadows(self, full: bool = True):
+        """bf16 copies of the weights (what the GEMMs read). ``full`` re-casts the whole arena (after loading a
+        checkpoint / init); the fused AdamW kernel keeps it current afterwards, only the padded conv operand
+        is re-made each step."""
+        enc, dec, _ = self._engines
+        if full:
+            ops.cast_bf16(self.arena.p, self.arena.pb)
+        enc.refresh_shadows()
+
+    # ------------------------------------------------------------------ compute
+    def encode(self, image_input: torch.Tensor):
+        enc, _, _ = self._ensure_engines()
+        assert image_input.shape[1:] == (self.in_chans, *self.img_size), \
+            f'image {tuple(image_input.shape)} does not match the configured {self.in_chans}x{self.img_size}'  # timm strict img size
+        enc32, enc16 = enc.forward(image_input.contiguous().float())
+        return enc32, enc16
+
+    def forward(self, image_input: torch.Tensor, text_input: torch.Tensor):
+        """ref models/cruller.py:14-21 -> output['logits'] bf16 [B, T, V] (a view of the padded logits buffer)."""
+        enc, dec, _ = self._ensure_engines()
+        enc32, enc16 = self.encode(image_input)
+        B, T = text_input.shape
+        logits = dec.forward(text_input.contiguous(), enc16, enc.out_tokens())
+        return CausalLMOutput(logits=logits.view(B, T, dec.Vp)[:, :, :self.vocab_size],
+                              encoder_last_hidden_state=enc32.view(B, enc.out_tokens(), -1))
+
+    def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0):
+        """forward + shifted-token cross-entropy; leaves d(loss*grad_mul)/dlogits in the logits buffer.
+        returns the device scalar loss (fp32, = mean NLL * loss_mul)."""
+        enc, dec, bufs = self._ensure_engines()
+        self.forward(image_input, text_input)
+        B, T = text_input.shape
+        M = B * T
+        logits = bufs.t['dec.logits']
+        self._loss = bufs.get('loss', (1,), torch.float32)
+        n_valid = bufs.get('n_valid', (1,), torch.int32)
+        row_loss = bufs.get('row_loss', (M,), torch.float32)
+        self._target = text_target.contiguous().view(-1)
+        ops.cross_entropy(logits, self._target, self.vocab_size, loss_mul, grad_mul, self._loss, n_valid, row_loss, logits)
+        return self._loss
+
+    def backward(self, on_ready: Optional[Callable[[str], None]] = None):
+        """backward of the last forward_loss(); weight gradients accumulate into arena.g.  ``on_ready(name)`` is
+        called as the sweep passes arena entry ``name``: every gradient at or after it (layout order) is final."""
+        enc, dec, bufs = self._ensure_engines()
+        assert self.arena.g is not None, 'call alloc_training_state() (train_setup) before backward'
+        S = enc.out_tokens()
+        denc = bufs.get('denc', (dec.B * S, dec.D), torch.float32)
+        denc.zero_()
+        dec.backward(bufs.t['dec.logits'], bufs.t[enc.tag + '.norm.y16'], denc, on_ready)
+        enc.backward(denc, on_ready)
+
+    def activation_bytes(self) -> int:
+        return 0 if self._engines is None else self._engines[2].bytes()

@@ -1,0 +1,194 @@
+"""Tensor-level wrappers over the C-ABI (pixparse_amd.hip).  PyTorch is only the owner of device
+memory and streams here: every function takes torch tensors, passes raw pointers + the current
+HIP stream, and returns nothing that was computed by torch."""
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import NT, NN, TN, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC  # noqa: F401
+
+BF16, F32 = torch.bfloat16, torch.float32
+VOCAB_PAD = 128   # logits row stride / embedding rows are padded to a multiple of this
+K_PAD = 64        # contraction dims of NT/NN GEMMs are padded to a multiple of this when needed
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda:
+        raise TypeError(f'{name}: expected a cuda {dtype} tensor, got {t.dtype} on {t.device}')
+
+
+def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
+         C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
+         ldaux: int = 0, resid: Optional[torch.Tensor] = None, ldr: int = 0) -> None:
+    _chk(A, BF16, 'gemm A')
+    _chk(B, BF16, 'gemm B')
+    hip.call('crl_gemm_bf16', layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(C), ldc, _p(aux), ldaux,
+             _p(resid), ldr, _stream())
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16,
+               aux: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+    """out[M, N] = x[M, K] @ w[N, K]^T (+bias) with the epilogue; x, w bf16 row-major 2-D (may be row-strided)."""
+    M, K = x.shape
+    N = n if n is not None else w.shape[0]
+    gemm(NT, epi, M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0), bias, aux,
+         aux.stride(0) if aux is not None else 0, resid, resid.stride(0) if resid is not None else 0)
+
+
+def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epi: int = EPI_BF16,
+                 aux: Optional[torch.Tensor] = None, k: Optional[int] = None) -> None:
+    """out[M, Kin] = dy[M, N] @ w[N, Kin]; contraction over N (= dy.shape[1])."""
+    M, N = dy.shape
+    Kin = k if k is not None else w.shape[1]
+    gemm(NN, epi, M, Kin, N, dy, dy.stride(0), w, w.stride(0), out, out.stride(0), None, aux,
+         aux.stride(0) if aux is not None else 0)
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool = True,
+                 n: Optional[int] = None, k: Optional[int] = None) -> None:
+    """dw[N, Kin] (+)= dy[M, N]^T @ x[M, Kin]  (fp32 output straight into the grad arena)."""
+    M = dy.shape[0]
+    N = n if n is not None else dy.shape[1]
+    Kin = k if k is not None else x.shape[1]
+    gemm(TN, EPI_F32_ACC if accumulate else EPI_F32, N, Kin, M, dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0))
+
+
+class Scratch:
+    """lazily grown device scratch shared by the reductions (never read across calls)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_scratch = Scratch()
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = True, n: Optional[int] = None) -> None:
+    M = x.shape[0]
+    N = n if n is not None else x.shape[1]
+    ws = _scratch.get(hip.query('crl_colsum_ws_bytes', N), x.device)
+    hip.call('crl_colsum_bf16', _p(x), M, N, x.stride(0), _p(out), int(accumulate), _p(ws), _stream())
+
+
+def layernorm_fwd(x, gamma, beta, eps, y_f32, y_bf16, mean, rstd) -> None:
+    M, D = x.shape
+    _chk(x, F32, 'layernorm x')
+    hip.call('crl_layernorm_fwd', _p(x), _p(gamma), _p(beta), float(eps), M, D, _p(y_f32), _p(y_bf16), _p(mean), _p(rstd),
+             _stream())
+
+
+def layernorm_bwd(dy_f32, dy_bf16, x, gamma, mean, rstd, dx_f32, dx_accumulate, dx_bf16, dgamma, dbeta,
+                  acc_wgrad: bool = True) -> None:
+    M, D = x.shape
+    ws = _scratch.get(hip.query('crl_layernorm_bwd_ws_bytes', D), x.device)
+    hip.call('crl_layernorm_bwd', _p(dy_f32), _p(dy_bf16), _p(x), _p(gamma), _p(mean), _p(rstd), M, D, _p(dx_f32),
+             int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), int(acc_wgrad), _p(ws), _stream())
+
+
+def _bs_rs(t: torch.Tensor):
+    """(batch stride, row stride) in elements of a [B, N, H*64-ish] view whose last dim is contiguous."""
+    assert t.dim() == 3 and t.stride(2) == 1, 'attention operands are [B, N, H*64] views with contiguous channels'
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool) -> None:
+    """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32."""
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    hip.call('crl_attn_fwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o), _p(lse),
+             B, heads, Nq, Nk, float(scale), int(causal), _stream())
+
+
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool) -> None:
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    hip.call('crl_attn_bwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o),
+             _p(d_o), *_bs_rs(d_o), _p(lse), _p(delta), _p(dq), *_bs_rs(dq), _p(dk), *_bs_rs(dk), _p(dv), *_bs_rs(dv),
+             B, heads, Nq, Nk, float(scale), int(causal), _stream())
+
+
+def swin_attn_fwd(qkv, table, out, B, Hf, Wf, heads, w, shift, scale) -> None:
+    hip.call('crl_swin_attn_fwd', _p(qkv), _p(table), _p(out), B, Hf, Wf, heads, w, shift, float(scale), _stream())
+
+
+def swin_attn_bwd(qkv, table, d_out, dqkv, dtable, B, Hf, Wf, heads, w, shift, scale) -> None:
+    hip.call('crl_swin_attn_bwd', _p(qkv), _p(table), _p(d_out), _p(dqkv), _p(dtable), B, Hf, Wf, heads, w, shift,
+             float(scale), _stream())
+
+
+def patch_merge_fwd(x, y, B, Hf, Wf, C) -> None:
+    hip.call('crl_patch_merge_fwd', _p(x), _p(y), B, Hf, Wf, C, _stream())
+
+
+def patch_merge_bwd(dy, dx, B, Hf, Wf, C) -> None:
+    hip.call('crl_patch_merge_bwd', _p(dy), _p(dx), B, Hf, Wf, C, _stream())
+
+
+def im2row(image, patches, P, gh, gw) -> None:
+    B, C, H, W = image.shape
+    _chk(image, F32, 'im2row image')
+    hip.call('crl_im2row', _p(image), _p(patches), B, C, H, W, P, gh, gw, patches.shape[1], _stream())
+
+
+def vit_tokens_fwd(patch, cls, pos, x, B, Np, D) -> None:
+    hip.call('crl_vit_tokens_fwd', _p(patch), _p(cls), _p(pos), _p(x), B, Np, D, _stream())
+
+
+def vit_tokens_bwd(dx, dpatch, dcls, dpos, B, Np, D, accumulate: bool = True) -> None:
+    hip.call('crl_vit_tokens_bwd', _p(dx), _p(dpatch), _p(dcls), _p(dpos), int(accumulate), B, Np, D, _stream())
+
+
+def embed_fwd(ids, tok, pos, out, pos_offset: int = 2) -> None:
+    B, T = ids.shape
+    hip.call('crl_embed_fwd', _p(ids), _p(tok), _p(pos), _p(out), B, T, out.shape[1], pos_offset, _stream())
+
+
+def embed_bwd(ids, dt, dtok, dpos, pos_offset: int = 2, accumulate: bool = True) -> None:
+    B, T = ids.shape
+    hip.call('crl_embed_bwd', _p(ids), _p(dt), _p(dtok), _p(dpos), int(accumulate), B, T, dt.shape[1], pos_offset, _stream())
+
+
+def cross_entropy(logits, target, V: int, loss_mul: float, grad_mul: float, loss, n_valid, row_loss, dlogits) -> None:
+    M = logits.shape[0]
+    hip.call('crl_cross_entropy', _p(logits), logits.stride(0), _p(target), M, V, float(loss_mul), float(grad_mul),
+             _p(loss), _p(n_valid), _p(row_loss), _p(dlogits), _stream())
+
+
+def grad_norm(g, max_norm: float, inv_scale: float, state) -> None:
+    ws = _scratch.get(hip.query('crl_grad_norm_ws_bytes'), g.device)
+    hip.call('crl_grad_norm', _p(g), g.numel(), float(max_norm), float(inv_scale), _p(state), _p(ws), _stream())
+
+
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step: int, state, zero_grad: bool) -> None:
+    hip.call('crl_adamw', _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
+             float(eps), float(weight_decay), int(step), _p(state), int(zero_grad), _stream())
+
+
+def cast_bf16(src, dst) -> None:
+    hip.call('crl_cast_bf16', _p(src), _p(dst), src.numel(), _stream())
+
+
+def cast_pad_bf16(src, dst, R: int, C: int, Cp: int) -> None:
+    hip.call('crl_cast_pad_bf16', _p(src), _p(dst), R, C, Cp, _stream())
+
+
+def add_bf16_to_f32(x_bf16, y, accumulate: bool) -> None:
+    hip.call('crl_add_bf16_to_f32', _p(x_bf16), _p(y), x_bf16.numel(), int(accumulate), _stream())

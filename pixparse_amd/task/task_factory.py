@@ -1,0 +1,26 @@
+"""name -> (TaskCls, CfgCls) registry (ref: task/task_factory.py:44-79).  Only the pretrain task is on the
+hot path; the reference's fine-tune / eval entries are 'next' rows and raise a clear error."""
+from ..framework import DeviceEnv, Monitor
+from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
+
+_NOT_BUILT = ('cruller_eval_ocr', 'cruller_eval_rvlcdip', 'cruller_eval_cord', 'cruller_eval_docvqa', 'donut_eval_ocr',
+              'cruller_finetune_rvlcdip', 'cruller_finetune_cord', 'cruller_finetune_docvqa', 'cruller_finetune_xent')
+
+
+class TaskFactory:
+    TASK_CLASS_REGISTRY = {
+        'cruller_pretrain': (TaskCrullerPretrain, TaskCrullerPretrainCfg),
+    }
+
+    @classmethod
+    def create_task(cls, task_name: str, task_args, device_env: DeviceEnv, monitor: Monitor):
+        task_name = task_name.lower()
+        if task_name in _NOT_BUILT:
+            raise NotImplementedError(f'task {task_name!r} exists in the reference but is outside the MI355X hot-path scope '
+                                      '(SURVEY.md §8f); only cruller_pretrain is built')
+        if task_name not in cls.TASK_CLASS_REGISTRY:
+            raise ValueError(f'Unknown task type: {task_name}. Available tasks are {list(cls.TASK_CLASS_REGISTRY.keys())}')
+        task_cls, task_cfg = cls.TASK_CLASS_REGISTRY[task_name]
+        task_cfg_instance = task_cfg(**(vars(task_args) if not isinstance(task_args, dict) else task_args))
+        task_cls_instance = task_cls(cfg=task_cfg_instance, device_env=device_env, monitor=monitor)
+        return task_cls_instance, task_cfg_instance

@@ -1,0 +1,88 @@
+"""Tokenizer config + wrapper (ref: tokenizers/config.py:14-17, tokenizers/tokenizer_hf.py:6-18).
+`facebook/bart-large` cannot be fetched offline, so when the HF files are not in the local cache a
+byte-level stand-in with BART's special ids (bos 0, pad 1, eos 2, vocab 50265) is used; it only feeds
+synthetic benches and tests -- real-data tokenisation is the f-1 'next' row of SURVEY §8."""
+from dataclasses import dataclass
+
+
+@dataclass
+class TokenizerCfg:
+    name: str = 'facebook/bart-large'
+    pretrained: bool = True
+
+
+class ByteBartTokenizer:
+    bos_token, pad_token, eos_token, unk_token = '<s>', '<pad>', '</s>', '<unk>'
+    bos_token_id, pad_token_id, eos_token_id, unk_token_id = 0, 1, 2, 3
+
+    def __init__(self, base_vocab: int = 50265):
+        self.base_vocab = base_vocab
+        self.added = {}
+
+    def add_special_tokens(self, d):
+        n = 0
+        for t in d.get('additional_special_tokens', []):
+            if t not in self.added:
+                self.added[t] = self.base_vocab + len(self.added)
+                n += 1
+        return n
+
+    def __len__(self):
+        return self.base_vocab + len(self.added)
+
+    def convert_tokens_to_ids(self, tok):
+        fixed = {self.bos_token: 0, self.pad_token: 1, self.eos_token: 2, self.unk_token: 3}
+        if tok in fixed:
+            return fixed[tok]
+        return self.added.get(tok, self.unk_token_id)
+
+    def __call__(self, text, add_special_tokens=False, return_tensors='pt', max_length=None, padding='max_length', truncation=True):
+        import torch
+        specials = dict(self.added)
+        specials.update({self.eos_token: 2, self.bos_token: 0, self.pad_token: 1})
+        ids, i = [], 0
+        while i < len(text):
+            for s, sid in specials.items():
+                if text.startswith(s, i):
+                    ids.append(sid)
+                    i += len(s)
+                    break
+            else:
+                for b in text[i].encode('utf-8'):
+                    ids.append(4 + b)
+                i += 1
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        if padding == 'max_length' and max_length is not None:
+            ids = ids + [self.pad_token_id] * (max_length - len(ids))
+
+        class _Enc:
+            pass
+        e = _Enc()
+        e.input_ids = torch.tensor([ids], dtype=torch.int64)
+        return e
+
+    def decode(self, ids, skip_special_tokens=False):
+        inv = {v: k for k, v in self.added.items()}
+        out = bytearray()
+        s = ''
+        for t in ids:
+            t = int(t)
+            if 4 <= t < 260:
+                out.append(t - 4)
+            else:
+                s += out.decode('utf-8', 'replace')
+                out = bytearray()
+                if not skip_special_tokens:
+                    s += inv.get(t, {0: '<s>', 1: '<pad>', 2: '</s>'}.get(t, ''))
+        return s + out.decode('utf-8', 'replace')
+
+
+class TokenizerHF:
+    def __init__(self, cfg: TokenizerCfg):
+        self.trunk = None
+        try:
+            import transformers
+            self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name, local_files_only=True)
+        except Exception:
+            self.trunk = ByteBartTokenizer()

@@ -1,0 +1,378 @@
+"""Per-kernel parity tests of libcruller_hip.so on a real MI355X (run with `-m gpu`).
+
+Every test calls the HIP kernel through the C-ABI (pixparse_amd.ops -> ctypes) and compares with a
+plain fp32 PyTorch restatement of the same op (computed with torch on the same device, or by the CPU
+oracle).  bf16 results are compared with tolerances that are stated next to each check.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from pixparse_amd import hip
+    hip.load()
+    return torch.device('cuda:0')
+
+
+def rnd(shape, dev, scale=1.0, seed=0, dtype=F32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def close(a, b, rtol, atol, what=''):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), f'{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (ref max {float(b.abs().max()):.4g})'
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('M,N,K', [(300, 264, 192), (129, 128, 64), (1000, 520, 96), (64, 8, 32), (257, 1024, 1024)])
+def test_gemm_nt_epilogues(dev, M, N, K):
+    from pixparse_amd import ops
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    ref = x.float() @ w.float().t() + bias.to(BF16).float()
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_fwd(x, w, bias, out)
+    close(out, ref, 1e-2, 1e-2, 'EPI_BF16')           # bf16 output rounding: 2^-8 relative
+    # GELU epilogue: aux = pre-activation, out = gelu(bf16(pre))
+    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    act = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=pre)
+    close(pre, ref, 1e-2, 1e-2, 'GELU aux')
+    close(act, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, 'GELU out')
+    # residual epilogue (fp32 out, in place on the residual)
+    resid = rnd((M, N), dev, 1.0, 4)
+    want = resid + ref.to(BF16).float()
+    y = resid.clone()
+    ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+    close(y, want, 1e-2, 2e-2, 'F32_RESID')
+    # no bias
+    ops.linear_fwd(x, w, None, out)
+    close(out, x.float() @ w.float().t(), 1e-2, 1e-2, 'no bias')
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 288, 192), (130, 96, 288), (1000, 544, 1024)])
+def test_gemm_nn_dgrad(dev, M, N, K):
+    """dx[M, K] = dy[M, N] @ w[N, K] (+ fused GELU backward)"""
+    from pixparse_amd import ops
+    dy = rnd((M, N), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    ref = dy.float() @ w.float()
+    out = torch.empty(M, K, dtype=BF16, device=dev)
+    ops.linear_dgrad(dy, w, out)
+    close(out, ref, 1e-2, 1e-2, 'NN')
+    h = rnd((M, K), dev, 1.0, 3, BF16)
+    hf = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hf).backward(ref.to(BF16).float())
+    ops.linear_dgrad(dy, w, out, ops.EPI_BF16_DGELU, aux=h)
+    close(out, hf.grad, 1e-2, 1e-2, 'NN + dGELU')
+    acc = rnd((M, K), dev, 1.0, 5)
+    want = acc + ref
+    ops.linear_dgrad(dy, w, acc, ops.EPI_F32_ACC)
+    close(acc, want, 1e-3, 1e-2, 'NN F32_ACC')
+
+
+@pytest.mark.parametrize('M,N,K', [(777, 264, 192), (64, 128, 128), (1000, 520, 96), (4999, 256, 588)])
+def test_gemm_tn_wgrad(dev, M, N, K):
+    """dw[N, K] = dy[M, N]^T @ x[M, K]; contraction over the ragged row count M"""
+    from pixparse_amd import ops
+    dy = rnd((M, N), dev, 1.0, 1, BF16)
+    Kp = (K + 63) // 64 * 64
+    xs = torch.zeros(M, Kp, dtype=BF16, device=dev)
+    xs[:, :K] = rnd((M, K), dev, 1.0, 2, BF16)
+    ref = dy.float().t() @ xs[:, :K].float()
+    dw = torch.full((N, K), 7.0, dtype=F32, device=dev)
+    ops.linear_wgrad(dy, xs, dw, accumulate=False, k=K)
+    close(dw, ref, 2e-3, 2e-2 * math.sqrt(M / 64), 'TN')     # fp32 accumulate of bf16 products
+    ops.linear_wgrad(dy, xs, dw, accumulate=True, k=K)
+    close(dw, 2 * ref, 2e-3, 4e-2 * math.sqrt(M / 64), 'TN accumulate')
+
+
+def test_gemm_strided_views_and_errors(dev):
+    from pixparse_amd import hip, ops
+    M, D = 200, 128
+    qkv = rnd((M, 3 * D), dev, 1.0, 1, BF16)
+    w = rnd((64, D), dev, 0.1, 2, BF16)
+    out = torch.empty(M, 64, dtype=BF16, device=dev)
+    ops.linear_fwd(qkv[:, D:2 * D], w, None, out)            # row-strided A
+    close(out, qkv[:, D:2 * D].float() @ w.float().t(), 1e-2, 1e-2, 'strided A')
+    with pytest.raises(hip.HipLibraryError):
+        ops.linear_fwd(rnd((8, 40), dev, 1, 1, BF16), rnd((8, 40), dev, 1, 2, BF16), None, torch.empty(8, 8, dtype=BF16, device=dev))  # K % 32
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm & row ops
+@pytest.mark.parametrize('M,D', [(37, 96), (1001, 1024), (5, 1536)])
+def test_layernorm(dev, M, D):
+    from pixparse_amd import ops
+    x = rnd((M, D), dev, 2.0, 1) + 0.5
+    gamma, beta = rnd((D,), dev, 0.2, 2) + 1.0, rnd((D,), dev, 0.2, 3)
+    y32 = torch.empty(M, D, device=dev)
+    y16 = torch.empty(M, D, dtype=BF16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, 1e-5, y32, y16, mean, rstd)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    close(y32, ref, 1e-5, 1e-5, 'ln fwd f32')
+    close(y16, ref, 1e-2, 1e-2, 'ln fwd bf16')
+    dy32 = rnd((M, D), dev, 1.0, 4)
+    dy16 = rnd((M, D), dev, 1.0, 5, BF16)
+    ref.backward(dy32 + dy16.float())
+    base = rnd((M, D), dev, 1.0, 6)
+    dx = base.clone()
+    dxb = torch.empty(M, D, dtype=BF16, device=dev)
+    dg, db = torch.ones(D, device=dev), torch.ones(D, device=dev)
+    ops.layernorm_bwd(dy32, dy16, x, gamma, mean, rstd, dx, True, dxb, dg, db, True)
+    close(dx, base + xr.grad, 1e-4, 1e-4, 'ln bwd dx (accumulated)')
+    close(dxb, base + xr.grad, 1e-2, 1e-2, 'ln bwd dx bf16 = bf16(final)')
+    close(dg, 1 + gr.grad, 1e-4, 1e-3, 'ln dgamma (+=)')
+    close(db, 1 + br.grad, 1e-4, 1e-3, 'ln dbeta (+=)')
+    # in-place: dy_f32 aliases dx_f32, no accumulate
+    d2 = dy32.clone()
+    ops.layernorm_bwd(d2, None, x, gamma, mean, rstd, d2, False, None, None, None, True)
+    xr2 = x.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr2, (D,), gamma, beta, 1e-5).backward(dy32)
+    close(d2, xr2.grad, 1e-4, 1e-4, 'ln bwd in place')
+
+
+def test_colsum_cast_add(dev):
+    from pixparse_amd import ops
+    x = rnd((1234, 264), dev, 1.0, 1, BF16)
+    out = torch.ones(264, device=dev)
+    ops.colsum(x, out, True)
+    close(out, 1 + x.float().sum(0), 1e-4, 1e-2, 'colsum')
+    s = rnd((1001,), dev, 3.0, 2)
+    d = torch.empty(1001, dtype=BF16, device=dev)
+    ops.cast_bf16(s, d)
+    assert torch.equal(d, s.to(BF16))
+    w = rnd((5, 7), dev, 1.0, 3)
+    dp = torch.full((5, 16), 3.0, dtype=BF16, device=dev)
+    ops.cast_pad_bf16(w, dp, 5, 7, 16)
+    assert torch.equal(dp[:, :7], w.to(BF16)) and float(dp[:, 7:].abs().max()) == 0.0
+    y = torch.ones(1001, device=dev)
+    ops.add_bf16_to_f32(d, y, True)
+    assert torch.equal(y, 1 + d.float())
+
+
+def test_embed_tokens_im2row_merge(dev):
+    from pixparse_amd import ops
+    B, T, D, V = 3, 17, 64, 99
+    ids = torch.randint(0, V, (B, T), device=dev)
+    tok, pos = rnd((V, D), dev, 1, 1), rnd((T + 2, D), dev, 1, 2)
+    out = torch.empty(B * T, D, device=dev)
+    ops.embed_fwd(ids, tok, pos, out)
+    assert torch.equal(out.view(B, T, D), tok[ids] + pos[torch.arange(T, device=dev) + 2])
+    dt = rnd((B * T, D), dev, 1, 3)
+    dtok, dpos = torch.zeros(V, D, device=dev), torch.ones(T + 2, D, device=dev)
+    ops.embed_bwd(ids, dt, dtok, dpos)
+    ref = torch.zeros(V, D, device=dev).index_add_(0, ids.view(-1), dt)
+    close(dtok, ref, 1e-5, 1e-5, 'embed scatter')
+    close(dpos[2:], 1 + dt.view(B, T, D).sum(0), 1e-5, 1e-5, 'embed dpos')
+    # ViT token assembly
+    Np = 6
+    patch = rnd((B * Np, D), dev, 1, 4, BF16)
+    cls, pe = rnd((1, 1, D), dev, 1, 5), rnd((1, Np + 1, D), dev, 1, 6)
+    x = torch.empty(B * (Np + 1), D, device=dev)
+    ops.vit_tokens_fwd(patch, cls, pe, x, B, Np, D)
+    want = torch.cat([cls.expand(B, -1, -1), patch.view(B, Np, D).float()], 1) + pe
+    assert torch.equal(x.view(B, Np + 1, D), want)
+    dx = rnd((B * (Np + 1), D), dev, 1, 7)
+    dpatch = torch.empty(B * Np, D, dtype=BF16, device=dev)
+    dcls, dpe = torch.zeros(1, 1, D, device=dev), torch.zeros(1, Np + 1, D, device=dev)
+    ops.vit_tokens_bwd(dx, dpatch, dcls, dpe, B, Np, D, True)
+    d3 = dx.view(B, Np + 1, D)
+    assert torch.equal(dpatch.view(B, Np, D), d3[:, 1:].to(BF16))
+    close(dpe[0], d3.sum(0), 1e-5, 1e-5, 'dpos')
+    close(dcls[0, 0], d3[:, 0].sum(0), 1e-5, 1e-5, 'dcls')
+    # im2row == unfold of the floor-cropped image, column order (c, ph, pw)
+    C, H, W, P = 3, 37, 50, 8
+    img = rnd((B, C, H, W), dev, 1, 8)
+    gh, gw = H // P, W // P
+    Kp = 256
+    patches = torch.empty(B * gh * gw, Kp, dtype=BF16, device=dev)
+    ops.im2row(img, patches, P, gh, gw)
+    ref = torch.nn.functional.unfold(img[:, :, :gh * P, :gw * P], P, stride=P).transpose(1, 2).reshape(B * gh * gw, C * P * P)
+    assert torch.equal(patches[:, :C * P * P], ref.to(BF16)) and float(patches[:, C * P * P:].abs().max()) == 0
+    # patch merge permutation
+    Hf, Wf, Cc = 6, 4, 8
+    xm = rnd((B, Hf, Wf, Cc), dev, 1, 9)
+    ym = torch.empty(B, Hf // 2, Wf // 2, 4 * Cc, device=dev)
+    ops.patch_merge_fwd(xm, ym, B, Hf, Wf, Cc)
+    want = xm.reshape(B, Hf // 2, 2, Wf // 2, 2, Cc).permute(0, 1, 3, 4, 2, 5).flatten(3)
+    assert torch.equal(ym, want)
+    back = torch.empty_like(xm)
+    ops.patch_merge_bwd(ym, back, B, Hf, Wf, Cc)
+    assert torch.equal(back, xm)
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale, causal):
+    """[B,H,N,d] fp32 restatement of the flash kernel: fp32 scores/softmax, P rounded to bf16 before P.V"""
+    s = q @ k.transpose(-1, -2) * scale
+    if causal:
+        nq, nk = s.shape[-2:]
+        s = s.masked_fill(~torch.ones(nq, nk, dtype=torch.bool, device=q.device).tril(nk - nq), float('-inf'))
+    p = torch.softmax(s, -1)
+    return p.to(BF16).float() @ v, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize('B,H,Nq,Nk,causal', [(2, 2, 200, 200, False), (1, 3, 127, 333, False), (2, 2, 255, 255, True),
+                                               (1, 8, 64, 64, False), (1, 1, 1, 70, False), (1, 2, 300, 300, True)])
+def test_attention_fwd_bwd(dev, B, H, Nq, Nk, causal):
+    from pixparse_amd import ops
+    d, D = 64, H * 64
+    scale = d ** -0.5
+    # fused qkv buffer for self-attention shapes (strided views), separate tensors otherwise
+    if Nq == Nk:
+        qkv = rnd((B, Nq, 3 * D), dev, 1.0, 1, BF16)
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    else:
+        q = rnd((B, Nq, D), dev, 1.0, 1, BF16)
+        kv = rnd((B, Nk, 2 * D), dev, 1.0, 2, BF16)
+        k, v = kv[:, :, :D], kv[:, :, D:]
+    o = torch.empty(B, Nq, D, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, Nq, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, causal)
+    hd = lambda t, n: t.float().reshape(B, n, H, d).transpose(1, 2)
+    qf, kf, vf = (hd(q, Nq).requires_grad_(True), hd(k, Nk).requires_grad_(True), hd(v, Nk).requires_grad_(True))
+    oref, lref = attn_ref(qf, kf, vf, scale, causal)
+    close(hd(o, Nq), oref, 2e-2, 2e-2, 'attn out')            # bf16 P and bf16 output
+    close(lse, lref, 1e-3, 2e-3, 'attn lse')
+    d_o = rnd((B, Nq, D), dev, 1.0, 5, BF16)
+    oref.backward(hd(d_o, Nq))
+    delta = torch.empty(B, H, Nq, device=dev)
+    if Nq == Nk:
+        dqkv = torch.zeros(B, Nq, 3 * D, dtype=BF16, device=dev)
+        dq, dk, dv = dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:]
+    else:
+        dq = torch.zeros(B, Nq, D, dtype=BF16, device=dev)
+        dkv = torch.zeros(B, Nk, 2 * D, dtype=BF16, device=dev)
+        dk, dv = dkv[:, :, :D], dkv[:, :, D:]
+    ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, H, scale, causal)
+    # gradients: bf16 storage of sums of ~N products of bf16-rounded factors
+    tol = 3e-2
+    close(hd(dq, Nq), qf.grad, tol, tol * float(qf.grad.abs().max()), 'dq')
+    close(hd(dk, Nk), kf.grad, tol, tol * float(kf.grad.abs().max()), 'dk')
+    close(hd(dv, Nk), vf.grad, tol, tol * float(vf.grad.abs().max()), 'dv')
+
+
+def test_attention_forced_rescale(dev):
+    """online-softmax rescale branch: one key far larger than the rest, placed in a late tile (guide rule 26)"""
+    from pixparse_amd import ops
+    B, H, N = 1, 1, 256
+    q = rnd((B, N, 64), dev, 1.0, 1, BF16)
+    k = rnd((B, N, 64), dev, 1.0, 2, BF16)
+    v = rnd((B, N, 64), dev, 1.0, 3, BF16)
+    k[0, 200] = (q[0, 17].float() * 4).to(BF16)       # spike for query 17 in the 4th key tile
+    o = torch.empty(B, N, 64, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, N, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, 0.125, False)
+    oref, lref = attn_ref(q.float()[:, None], k.float()[:, None], v.float()[:, None], 0.125, False)
+    close(o, oref[:, 0], 2e-2, 2e-2, 'spiked attn out')
+    close(lse, lref, 1e-3, 2e-3, 'spiked lse')
+
+
+@pytest.mark.parametrize('Hf,Wf,heads,w,shift', [(14, 14, 3, 7, 0), (14, 14, 3, 7, 3), (8, 16, 2, 4, 2), (7, 7, 4, 7, 0)])
+def test_swin_window_attention(dev, Hf, Wf, heads, w, shift):
+    from oracle import ref_cpu as R
+    from pixparse_amd import ops
+    B, hd = 2, 32
+    C = heads * hd
+    scale = hd ** -0.5
+    qkv = rnd((B, Hf, Wf, 3 * C), dev, 1.0, 1, BF16)
+    table = rnd(((2 * w - 1) ** 2, heads), dev, 0.5, 2)
+    out = torch.empty(B, Hf, Wf, C, dtype=BF16, device=dev)
+    ops.swin_attn_fwd(qkv, table, out, B, Hf, Wf, heads, w, shift, scale)
+    # oracle: roll -> window partition -> attention with rel-pos bias + shift mask -> reverse -> roll back
+    qc = qkv.float().cpu().requires_grad_(True)
+    tc = table.cpu().requires_grad_(True)
+    h = torch.roll(qc, (-shift, -shift), (1, 2)) if shift else qc
+    nW = (Hf // w) * (Wf // w)
+    hw = h.view(B, Hf // w, w, Wf // w, w, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, w * w, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    bias = tc[R.swin_relative_position_index(w).view(-1)].view(w * w, w * w, heads).permute(2, 0, 1).unsqueeze(0)
+    mask = R.swin_shift_mask(Hf, Wf, w, shift)
+    if mask is not None:
+        bias = bias + mask.repeat(B, 1, 1).unsqueeze(1)
+    o = R._attention(hw[0], hw[1], hw[2], scale, False, 'bf16', bias=bias)
+    o = o.transpose(1, 2).reshape(B * nW, w * w, C).view(B, Hf // w, Wf // w, w, w, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hf, Wf, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    close(out.cpu(), o.detach(), 2e-2, 2e-2, 'swin attn out')
+    d_out = rnd((B, Hf, Wf, C), dev, 1.0, 3, BF16)
+    o.backward(d_out.float().cpu())
+    dqkv = torch.zeros_like(qkv)
+    dtable = torch.zeros_like(table)
+    ops.swin_attn_bwd(qkv, table, d_out, dqkv, dtable, B, Hf, Wf, heads, w, shift, scale)
+    close(dqkv.cpu(), qc.grad, 3e-2, 3e-2 * float(qc.grad.abs().max()), 'swin dqkv')
+    close(dtable.cpu(), tc.grad, 2e-2, 2e-2 * float(tc.grad.abs().max()), 'swin dtable')
+
+
+# ------------------------------------------------------------------------------------------- loss / optimiser
+@pytest.mark.parametrize('M,V', [(37, 515), (300, 1027), (64, 50267)])
+def test_cross_entropy(dev, M, V):
+    from pixparse_amd import ops
+    Vp = (V + 127) // 128 * 128
+    logits = torch.zeros(M, Vp, dtype=BF16, device=dev)
+    logits[:, :V] = rnd((M, V), dev, 2.0, 1, BF16)
+    logits[:, V:] = 55.0                                 # garbage in the padded columns must be ignored
+    target = torch.randint(0, V, (M,), device=dev)
+    target[::5] = -100
+    lf = logits[:, :V].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, target, ignore_index=-100)
+    (ref * 8.0).backward()
+    loss = torch.zeros(1, device=dev)
+    nv = torch.zeros(1, dtype=torch.int32, device=dev)
+    rl = torch.empty(M, device=dev)
+    ops.cross_entropy(logits, target, V, 0.5, 8.0, loss, nv, rl, logits)
+    assert int(nv) == int((target != -100).sum())
+    assert abs(float(loss) - 0.5 * float(ref)) < 1e-5 * abs(float(ref)) + 1e-6
+    close(logits[:, :V], lf.grad, 1e-2, 1e-2 * float(lf.grad.abs().max()), 'dlogits')
+    assert float(logits[:, V:].abs().max()) == 0.0
+    # all targets ignored -> NaN loss like torch, zero gradient
+    target[:] = -100
+    ops.cross_entropy(logits, target, V, 1.0, 1.0, loss, nv, rl, logits)
+    assert math.isnan(float(loss)) and float(logits.abs().max()) == 0.0
+
+
+def test_grad_norm_adamw(dev, golden_dir):
+    import json
+    import os
+    from safetensors.torch import load_file
+    from pixparse_amd import ops
+    t = load_file(os.path.join(golden_dir, 'g5_optim.safetensors'))
+    meta = json.load(open(os.path.join(golden_dir, 'g5_optim.json')))
+    n = meta['n_tensors']
+    flat = lambda pre: torch.cat([t[f'{pre}.{i}'].reshape(-1) for i in range(n)]).to(dev)
+    p = flat('p0')
+    N = p.numel()
+    pad = (-N) % 4
+    p = torch.cat([p, torch.zeros(pad, device=dev)])
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.empty(p.numel(), dtype=BF16, device=dev)
+    state = torch.zeros(4, device=dev)
+    for step in range(3):
+        g = torch.cat([flat(f'g{step}') * 4.0, torch.zeros(pad, device=dev)])     # pretend loss scale 4
+        ops.grad_norm(g, meta['clip'], 0.25, state)
+        assert abs(float(state[0]) - meta['grad_norms'][step]) < 1e-5 * meta['grad_norms'][step]
+        ops.adamw(p, g, m, v, pb, meta['lr'], meta['betas'][0], meta['betas'][1], meta['eps'], 0.0, step + 1, state, True)
+        close(p[:N], flat(f'p{step + 1}'), 1e-6, 1e-7, f'adamw step {step}')
+        assert torch.equal(pb, p.to(BF16)) and float(g.abs().max()) == 0.0
+    # inf in the grads -> step skipped, flag raised
+    g = torch.ones_like(p)
+    g[3] = float('inf')
+    before = p.clone()
+    ops.grad_norm(g, 1.0, 1.0, state)
+    ops.adamw(p, g, m, v, pb, 1e-3, 0.9, 0.98, 1e-6, 0.0, 4, state, False)
+    assert float(state[2]) == 1.0 and torch.equal(p, before)
