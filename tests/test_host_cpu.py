@@ -1,0 +1,319 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol of include/crl.h,
+the reference plug-in surface (registry, cfg, counters, state_dict keys), arenas, schedule / scaler
+logic, the data contract against the reference's own preprocess outputs, and the bucketed gradient
+reducer on 2 gloo ranks.  No compute call is made (there is no GPU here)."""
+import json
+import os
+import re
+import random
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------- C-ABI
+def _header_decls():
+    src = open(os.path.join(ROOT, 'include', 'crl.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r'\b(?:int|size_t|const char\*)\s+(crl_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ('', 'void') else len([a for a in args.split(',') if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    from pixparse_amd import hip
+    ge.build()
+    decls = _header_decls()
+    assert len(decls) >= 26
+    lib = hip.load()
+    for name, nargs in decls.items():
+        assert hasattr(lib, name), f'{name} declared in crl.h but not exported'
+        assert name in hip.SIGNATURES, f'{name} has no ctypes signature'
+        assert len(hip.SIGNATURES[name][1]) == nargs, f'{name}: ctypes binds {len(hip.SIGNATURES[name][1])} args, header declares {nargs}'
+    assert set(hip.SIGNATURES) == set(decls)
+    assert hip.query('crl_version') == 1
+    assert hip.query('crl_layernorm_bwd_ws_bytes', 1024) == 512 * 2 * 1024 * 4
+    assert hip.query('crl_grad_norm_ws_bytes') > 0
+
+
+def test_argument_validation_without_gpu():
+    """error paths that return before any launch: wrong shapes come back as HipLibraryError with the text"""
+    from pixparse_amd import hip
+    hip.load()
+    with pytest.raises(hip.HipLibraryError, match='multiple of 32'):
+        hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, None)
+    with pytest.raises(hip.HipLibraryError, match='empty'):
+        hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, None)
+    with pytest.raises(hip.HipLibraryError, match='window'):
+        hip.call('crl_swin_attn_fwd', 16, 16, 16, 1, 18, 18, 1, 9, 0, 0.1, None)
+
+
+# ------------------------------------------------------------------------------------------- model surface
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    from oracle import ref_cpu as R
+    from pixparse_amd.models import Cruller, get_model_config
+    cfg = get_model_config('cruller_small')
+    model = Cruller(cfg, vocab_size=1027)
+    spec = R.ModelSpec('swin_tiny_patch4_window7_224', 'facebook/bart-base', 2, 128, (224, 224), 3, vocab=1027)
+    sd = model.state_dict()
+    want = spec.param_shapes()
+    got = {k: tuple(v.shape) for k, v in sd.items() if not k.endswith('lm_head.weight')}
+    assert got == want
+    assert sd['text_decoder.trunk.lm_head.weight'].data_ptr() == sd['text_decoder.trunk.model.decoder.embed_tokens.weight'].data_ptr()
+    assert model.image_encoder.trunk.pretrained_cfg['mean'] == (0.485, 0.456, 0.406)
+    # parameters are views of ONE flat arena, 16-byte aligned
+    base = model.arena.p.data_ptr()
+    for n, p in model.named_parameters():
+        assert base <= p.data_ptr() < base + model.arena.total * 4 and (p.data_ptr() - base) % 256 == 0
+    # checkpoint interchange: load an oracle-initialised state dict by name
+    params = R.init_params(spec, seed=3)
+    params['text_decoder.trunk.lm_head.weight'] = params['text_decoder.trunk.model.decoder.embed_tokens.weight']
+    model.load_state_dict(params)
+    assert torch.equal(model.arena.param('image_encoder.trunk.norm.weight'), params['image_encoder.trunk.norm.weight'])
+
+
+@pytest.mark.parametrize('name,enc,dec,layers,L,img,ch', [
+    ('cruller_base', 'vit_base_patch16_224', 'facebook/bart-base', 4, 1024, (576, 448), 1),
+    ('cruller_large_1280x960', 'vit_large_patch14_clip_224.datacompxl', 'facebook/bart-large', 10, 1024, (1280, 960), 3)])
+def test_large_config_layouts_without_materialising(name, enc, dec, layers, L, img, ch):
+    from oracle import ref_cpu as R
+    from pixparse_amd.layers.engines import BartEngine, ViTEngine
+    from pixparse_amd.models import get_model_config
+    from pixparse_amd.models.archs import BART_ARCHS, VIT_ARCHS
+    cfg = get_model_config(name)
+    assert cfg.image_encoder.name == enc and cfg.text_decoder.num_decoder_layers == layers and tuple(cfg.image_encoder.image_size) == img
+    spec = R.ModelSpec(enc, dec, layers, L, img, ch, vocab=50267)
+    mine = {('image_encoder.trunk.' + i[0]): tuple(i[1]) for i in ViTEngine.param_shapes(VIT_ARCHS[enc], ch, img)}
+    mine.update({('text_decoder.trunk.' + i[0]): tuple(i[1]) for i in BartEngine.param_shapes(BART_ARCHS[dec], layers, 50267, L)})
+    assert mine == spec.param_shapes()
+    n = sum(int(torch.tensor(s).prod()) for s in mine.values())
+    if name.startswith('cruller_large'):
+        assert abs(n - 529.7e6) < 0.5e6          # 529.7 M parameters
+
+
+def test_no_cpu_fallback():
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.models import Cruller, get_model_config
+    from pixparse_amd.task import TaskFactory
+    model = Cruller(get_model_config('cruller_small'), vocab_size=515)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model(torch.zeros(1, 3, 224, 224), torch.zeros(1, 8, dtype=torch.int64))
+    with pytest.raises(TypeError):
+        model.to(torch.bfloat16)
+    with pytest.raises(ValueError):
+        TaskFactory.create_task('nope', {}, DeviceEnv('cpu'), None)
+    with pytest.raises(NotImplementedError):
+        TaskFactory.create_task('cruller_eval_ocr', {}, DeviceEnv('cpu'), None)
+
+
+def test_task_surface_and_counters_cpu():
+    """constructor side of the plug-in (runs without a GPU); train_setup refuses a CPU device loudly"""
+    from types import SimpleNamespace
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    from pixparse_amd.models.archs import register_arch
+    from pixparse_amd.task import TaskCrullerPretrain, TaskFactory
+    register_arch('vit', 'vit_cpu_t', dict(patch=8, dim=64, depth=1, heads=1, mlp_ratio=2, ln_eps=1e-6, pre_norm=False, mean=(0.5,) * 3, std=(0.5,) * 3))
+    register_arch('bart', 'bart_cpu_t', dict(d_model=64, heads=1, ffn=128, ln_eps=1e-5, vocab=50265, dropout=0.0))
+    mcfg = ModelCfg(ImageEncoderCfg('vit_cpu_t', 'L', (32, 24), False), TextDecoderCfg('bart_cpu_t', False, 1, 16))
+    args = SimpleNamespace(num_intervals=3, num_warmup_intervals=1, eval_frequency=7, opt=OptimizationCfg(grad_accum_steps=2),
+                           dtype='bfloat16', amp=True, model_name=None, model=mcfg)
+    task, cfg = TaskFactory.create_task('cruller_pretrain', args, DeviceEnv('cpu'), None)
+    assert isinstance(task, TaskCrullerPretrain) and cfg.model_name == 'custom'
+    assert (task.step, task.batch_idx, task.interval_idx, task.interval_batch_idx, task.start_interval) == (0, 0, 0, 0, 0)
+    assert task.num_intervals == 3 and task.eval_frequency == 7 and task.vocab_size == 50267
+    assert task.model.state_dict()['text_decoder.trunk.model.decoder.embed_tokens.weight'].shape == (50267, 64)
+    assert task.num_image_chs == 1 and abs(task.img_mean - 0.5) < 1e-12
+    x = task.image_preprocess_train(torch.rand(1, 40, 30))
+    assert x.shape == (1, 32, 24)
+    with pytest.raises(RuntimeError, match='MI355X'):
+        task.train_setup(10)
+    with pytest.raises(NotImplementedError):
+        TaskFactory.create_task('cruller_pretrain', SimpleNamespace(**{**vars(args), 'dtype': 'float16'}), DeviceEnv('cpu'), None)
+
+
+# ------------------------------------------------------------------------------------------- schedule / scaler / data
+def test_cosine_schedule_matches_golden(golden_dir):
+    from pixparse_amd.framework.optim import CosineLRScheduler
+    meta = json.load(open(os.path.join(golden_dir, 'g5_optim.json')))['sched']
+
+    class Opt:
+        param_groups = [dict(lr=meta['base'], initial_lr=meta['base'])]
+    s = CosineLRScheduler(Opt, t_initial=meta['t_initial'], warmup_t=meta['warmup_t'])
+    for t, lr in meta['lrs'].items():
+        s.step_update(int(t))
+        assert abs(Opt.param_groups[0]['lr'] - lr) < 1e-15
+
+
+def test_loss_scaler_bookkeeping():
+    from pixparse_amd.framework.optim import LossScaler
+    sc = LossScaler(growth_interval=3)
+    assert sc.get_scale() == 65536.0
+
+    class Ev:
+        def query(self):
+            return True
+    for flag, want in [(0.0, 65536.0), (0.0, 65536.0), (0.0, 131072.0), (1.0, 65536.0), (0.0, 65536.0)]:
+        sc._pending.append((Ev(), torch.tensor([flag])))
+        sc.update()
+        assert sc.get_scale() == want
+    assert LossScaler(enabled=False).get_scale() == 1.0
+
+
+class _StubTok:
+    """the tokenizer tests/golden/make_golden.py used to run the reference's preprocess.py"""
+    pad_token_id, eos_token = 1, '</s>'
+    specials = {'</s>': 2, '<s_pretrain>': 50266, '<sep/>': 50265}
+
+    def convert_tokens_to_ids(self, t):
+        return self.specials[t]
+
+    def __call__(self, text, add_special_tokens=False, return_tensors='pt', max_length=None, padding='max_length', truncation=True):
+        ids, i = [], 0
+        while i < len(text):
+            for s, sid in self.specials.items():
+                if text.startswith(s, i):
+                    ids.append(sid)
+                    i += len(s)
+                    break
+            else:
+                ids.append(ord(text[i]) + 100)
+                i += 1
+        ids = (ids[:max_length] + [1] * max_length)[:max_length]
+        return type('E', (), {'input_ids': torch.tensor([ids])})()
+
+
+def test_preprocess_matches_reference_outputs(golden_dir):
+    from pixparse_amd.data import preprocess_ocr_anno, preprocess_text_anno
+    cases = json.load(open(os.path.join(golden_dir, 'g3_preprocess.json')))
+    tok = _StubTok()
+    for c in cases:
+        if c['fn'] == 'ocr':
+            out, meta = preprocess_ocr_anno(c['anno'], tok, c['L'], '<s_pretrain>', '<s_pretrain>', generator=random.Random(0))
+            assert meta == c['meta']
+        else:
+            out = preprocess_text_anno(c['anno'], tok, c['L'], '<s_pretrain>', '<s_pretrain>')
+        assert out['text'][0].tolist() == c['text'] and out['target'][0].tolist() == c['target']
+    with pytest.raises(RuntimeError):
+        preprocess_ocr_anno({'pages': []}, tok, 8, '<s_pretrain>', '<s_pretrain>', generator=random.Random(0))
+    with pytest.raises(RuntimeError):
+        preprocess_ocr_anno({'pages': [{'text': []}, {'text': []}]}, tok, 8, '<s_pretrain>', '<s_pretrain>', generator=random.Random(0))
+
+
+def test_synthetic_loader_contract():
+    from pixparse_amd.data import SyntheticLoaderBundle
+    lb = SyntheticLoaderBundle(batch_size=2, num_batches=3, in_chans=1, img_size=(32, 24), max_length=16, vocab_size=50267)
+    lb.set_interval(0)
+    batches = list(lb.loader)
+    assert len(batches) == 3 == lb.num_batches and lb.num_samples == 6
+    img, text, tgt = batches[0]
+    assert img.shape == (2, 1, 32, 24) and text.shape == (2, 16) and text.dtype == torch.int64
+    assert (text[:, 0] == 50266).all() and (text[:, -1] == 2).all() and (tgt[:, 0] == -100).all() and (tgt[:, 1:] == text[:, 1:]).all()
+
+
+def test_byte_tokenizer_roundtrip():
+    from pixparse_amd.tokenizers import ByteBartTokenizer
+    t = ByteBartTokenizer()
+    assert t.add_special_tokens({'additional_special_tokens': sorted({'<sep/>', '<s_pretrain>'})}) == 2 and len(t) == 50267
+    ids = t('<s_pretrain>héllo</s>', max_length=16).input_ids[0]
+    assert ids[0] == t.convert_tokens_to_ids('<s_pretrain>') and 2 in ids.tolist() and ids[-1] == 1
+    assert t.decode(ids, skip_special_tokens=True) == 'héllo'
+
+
+# ------------------------------------------------------------------------------------------- arena + reducer (gloo, 2 ranks)
+def _make_arena():
+    from pixparse_amd.layers.arena import ParamArena
+    from pixparse_amd.layers.engines import BartEngine
+    a = ParamArena()
+    a.add('enc.w', (33, 7))
+    for item in BartEngine.param_shapes(dict(d_model=64, heads=1, ffn=128, ln_eps=1e-5), 2, 131, 16):
+        a.add(item[0], item[1], item[2] if len(item) > 2 else None)
+    a.materialize('cpu')
+    return a
+
+
+def test_arena_layout_and_fused_views():
+    from pixparse_amd.layers.engines import BartEngine, Buffers
+    a = _make_arena()
+    a.alloc_training_state()
+    offs = [e.offset for e in a.entries.values()]
+    assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+    e = a.entries['model.decoder.embed_tokens.weight']
+    assert e.alloc == 256 * 64 and e.numel == 131 * 64            # vocab rows padded to a multiple of 128
+    eng = BartEngine(dict(d_model=64, heads=1, ffn=128, ln_eps=1e-5), 2, 131, 16, a, '', Buffers('cpu'))
+    a.pb = torch.zeros(a.total, dtype=torch.bfloat16)
+    lp = 'model.decoder.layers.1.'
+    w = eng.fw('p', lp, 'self_attn', 'q_proj', 3)
+    a.param(lp + 'self_attn.k_proj.weight').fill_(2.0)
+    a.param(lp + 'self_attn.v_proj.bias').fill_(3.0)
+    assert w.shape == (192, 64) and float(w[64:128].min()) == 2.0 and float(w[:64].abs().max()) == 0 and float(w[128:].abs().max()) == 0
+    assert float(eng.fb('p', lp, 'self_attn', 'q_proj', 3)[128:].min()) == 3.0
+    kv = eng.fw('g', lp, 'encoder_attn', 'k_proj', 2)
+    assert kv.data_ptr() == a.grad(lp + 'encoder_attn.k_proj.weight').data_ptr() and kv.shape == (128, 64)
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.framework.reducer import BucketedGradReducer
+    env = DeviceEnv('cpu')
+    assert env.world_size == world and env.global_rank == rank
+    a = _make_arena()
+    a.alloc_training_state()
+    torch.manual_seed(100 + rank)
+    a.p.normal_()
+    red = BucketedGradReducer(a, world, bucket_bytes=16 << 10)
+    red.broadcast_params(0)
+    p_sum = a.p.clone()
+    dist.all_reduce(p_sum)
+    ok = bool(torch.allclose(p_sum, a.p * world))
+    # buckets tile the arena exactly once, last bucket first
+    cover = torch.zeros(a.total)
+    for s, e in red.buckets:
+        cover[s:e] += 1
+    ok &= bool((cover == 1).all()) and red.buckets[0][1] == a.total and len(red.buckets) > 3
+    g_local = torch.randn(a.total, generator=torch.Generator().manual_seed(7 + rank))
+    a.g.copy_(g_local)
+    expect = sum(torch.randn(a.total, generator=torch.Generator().manual_seed(7 + r)) for r in range(world))
+    names = list(a.entries)
+    red.begin()
+    fired = []
+    for name in reversed(names):            # the backward sweep reports entries from the end of the arena
+        red.on_ready(name)
+        fired.append(red._next)
+    ok &= fired == sorted(fired) and 0 < fired[len(fired) // 2] < len(red.buckets)   # overlap: buckets fire progressively
+    red.finish()
+    ok &= bool(torch.allclose(a.g, expect, atol=1e-5)) and red.grad_divisor() == world
+    # no_sync micro-step: nothing is exchanged
+    a.g.copy_(g_local)
+    red.enabled = False
+    red.begin()
+    for name in reversed(names):
+        red.on_ready(name)
+    red.finish()
+    ok &= bool(torch.equal(a.g, g_local)) and red.grad_divisor() == 1.0
+    obj = env.broadcast_object({'date': 'x'} if rank == 0 else None)
+    ok &= obj == {'date': 'x'} and len(env.all_gather_object(rank)) == world
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_two_gloo_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + random.randint(0, 2000)
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
