@@ -79,6 +79,11 @@ def test_decoder_engine_vs_transformers_golden(dev, golden_dir):
     assert rel(denc.view(B, S, -1), t['out.grad_enc']) < 3e-2
     for name, gn in meta['grad_norms'].items():
         g = arena.grad(name)
+        if name.endswith('k_proj.bias'):
+            # d loss / d k-bias is identically zero (a key bias shifts every score of a row equally and softmax is
+            # shift invariant): both sides hold only rounding noise, so compare against the q-bias scale instead
+            assert float(g.norm()) < 5e-2 * meta['grad_norms'][name.replace('k_proj', 'q_proj')], name
+            continue
         assert abs(float(g.norm()) - gn) <= 3e-2 * gn + 1e-6, (name, float(g.norm()), gn)
 
 
@@ -118,6 +123,9 @@ def test_cruller_forward_backward_vs_oracle(dev, enc, img, fmt):
     worst = []
     for k in params:
         g, og = model.arena.grad(k), op[k].grad
+        if k.endswith('k_proj.bias'):   # mathematically zero gradient (softmax shift invariance): noise on both sides
+            assert float(g.norm()) < 5e-2 * float(op[k.replace('k_proj', 'q_proj')].grad.norm()), k
+            continue
         worst.append((rel(g, og), k))
     worst.sort(reverse=True)
     # gradients are sums of bf16-rounded products: 5% relative L2 per tensor, 2% on the total norm
