@@ -47,10 +47,16 @@ const char* crl_last_error(void);
 enum { CRL_NT = 0, CRL_NN = 1, CRL_TN = 2 };
 enum { CRL_EPI_BF16 = 0, CRL_EPI_BF16_GELU = 1, CRL_EPI_BF16_DGELU = 2, CRL_EPI_F32_RESID = 3,
        CRL_EPI_F32 = 4, CRL_EPI_F32_ACC = 5 };
+/* ws (optional, >= crl_gemm_ws_bytes(...)): fp32 scratch that lets the wgrad layout split its long
+ * contraction over several workgroups per output tile (deterministic slab reduce, no atomics). */
+size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K);
+/* kernel selection override for tests: 0 = auto (256x256 8-phase kernel when it fills the chip, else 128x128),
+ * 1 = always 128x128, 2 = 256x256 whenever legal. */
+int crl_gemm_set_policy(int policy);
 int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
-                  const float* resid, int64_t ldr, void* stream);
+                  const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream);
 
 /* column sums of a bf16 matrix into fp32 (bias gradients): out[n] (+)= sum_m X[m,n].
  * ws: >= crl_colsum_ws_bytes(N) bytes of scratch. */

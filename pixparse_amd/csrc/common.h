@@ -69,6 +69,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// ---- LDS-DMA issued from inline asm.  hipcc does not see these loads, so it neither drains them with a
+// conservative `s_waitcnt vmcnt(0)` in front of later LDS reads (it does that for the builtin form whenever the
+// read is a ds_read_b64_tr_b16) nor counts them: every wait on them is an explicit, counted s_waitcnt in the kernel.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 make_srd(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  u32x4 r;
+  r[0] = (uint32_t)a; r[1] = (uint32_t)(a >> 32) & 0xffffu; r[2] = bytes; r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// 16 B per lane: LDS[lds_base + 16*lane] <- buffer[voff + soff]   (zeros when out of range)
+__device__ __forceinline__ void dma16(u32x4 srd, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of the logical tile order (guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -14,75 +14,12 @@
 // row-contiguous epilogue stores.
 #include "common.h"
 
+#include "gemm_common.h"
+
 namespace {
+using namespace gemmc;
 
 constexpr int BM = 128, BN = 128, NT_THREADS = 256;
-
-struct GemmArgs {
-  const u16* A; const u16* B; const float* bias; void* C; void* aux; const float* resid;
-  int M, N, K;
-  int lda, ldb, ldc, ldaux, ldr;
-  uint32_t a_bytes, b_bytes;
-  int ntm, ntn;
-};
-
-// ---- swizzles (see the bank analysis in DESIGN.md "GEMM LDS images") ----
-template <int BK> __device__ __forceinline__ int km_swz(int row) {
-  return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
-}
-__device__ __forceinline__ int tr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
-
-// Issue the LDS-DMA for one operand tile.  KM: tile rows = matrix rows r0.., k contiguous from k0.
-template <int BK>
-__device__ __forceinline__ void stage_km(__amdgpu_buffer_rsrc_t rs, char* lds, int r0, int k0, int ld,
-                                         int tid, int wave) {
-  constexpr int CPR = BK / 8;                   // 16-B chunks per row
-  constexpr int NCH = 128 * CPR / NT_THREADS;   // chunks per thread
-#pragma unroll
-  for (int it = 0; it < NCH; ++it) {
-    const int c = it * NT_THREADS + tid;
-    const int row = c / CPR, ps = c % CPR;
-    const int ls = ps ^ km_swz<BK>(row);
-    const uint32_t off = ((uint32_t)(r0 + row) * (uint32_t)ld + (uint32_t)(k0 + ls * 8)) * 2u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
-  }
-}
-// TR: tile rows = contraction index k0.., columns c0.. of the matrix (128 of them).
-template <int BK>
-__device__ __forceinline__ void stage_tr(__amdgpu_buffer_rsrc_t rs, char* lds, int k0, int c0, int ld,
-                                         int tid, int wave) {
-  constexpr int NCH = BK * 16 / NT_THREADS;
-#pragma unroll
-  for (int it = 0; it < NCH; ++it) {
-    const int c = it * NT_THREADS + tid;
-    const int row = c >> 4, pc = c & 15;
-    const int lc = pc ^ tr_swz(row);
-    const uint32_t off = ((uint32_t)(k0 + row) * (uint32_t)ld + (uint32_t)(c0 + lc * 8)) * 2u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
-  }
-}
-
-// fragment (8 bf16 along k) for the 16 rows/cols [base, base+16) of a staged tile, k-step ks
-template <int BK>
-__device__ __forceinline__ bf16x8 frag_km(const char* lds, int base, int ks, int lane) {
-  const int row = base + (lane & 15), g = lane >> 4;
-  const int slot = ks * 4 + g;
-  const int addr = row * (BK * 2) + ((slot ^ km_swz<BK>(row)) << 4);
-  return *reinterpret_cast<const bf16x8*>(lds + addr);
-}
-__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int base, int ks, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int col = base + 4 * p;
-  const int k1 = ks * 32 + 8 * g + q;
-  const int a1 = k1 * 256 + ((((col >> 3)) ^ tr_swz(k1)) << 4) + (col & 7) * 2;
-  const int k2 = k1 + 4;
-  const int a2 = k2 * 256 + ((((col >> 3)) ^ tr_swz(k2)) << 4) + (col & 7) * 2;
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a1));
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a2));
-  typedef short short8v __attribute__((ext_vector_type(8)));
-  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, both);
-}
 
 template <int LAYOUT, int EPI, int BK>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
@@ -108,23 +45,25 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk_all = (g.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * g.kchunk;
+  const int nk = min(nk_all, kt0 + g.kchunk);
 
   auto stage = [&](int buf, int kt) {
     char* la = smem + buf * 2 * TILE_BYTES;
     char* lb = la + TILE_BYTES;
-    if constexpr (A_TR) stage_tr<BK>(ra, la, kt * BK, m0, g.lda, tid, wave);
-    else stage_km<BK>(ra, la, m0, kt * BK, g.lda, tid, wave);
-    if constexpr (B_TR) stage_tr<BK>(rb, lb, kt * BK, n0, g.ldb, tid, wave);
-    else stage_km<BK>(rb, lb, n0, kt * BK, g.ldb, tid, wave);
+    if constexpr (A_TR) stage_tr<BK, NT_THREADS>(ra, la, kt * BK, m0, g.lda, tid, wave);
+    else stage_km<BK, NT_THREADS>(ra, la, m0, kt * BK, g.lda, tid, wave);
+    if constexpr (B_TR) stage_tr<BK, NT_THREADS>(rb, lb, kt * BK, n0, g.ldb, tid, wave);
+    else stage_km<BK, NT_THREADS>(rb, lb, n0, kt * BK, g.ldb, tid, wave);
   };
 
-  stage(0, 0);
+  stage(0, kt0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* la = smem + cur * 2 * TILE_BYTES;
     const char* lb = la + TILE_BYTES;
@@ -188,7 +127,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
         float4 o{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
         *reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n) = o;
       } else if constexpr (EPI == CRL_EPI_F32) {
-        *reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4*>((float*)g.C + blockIdx.y * g.slab_stride + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
       } else {  // CRL_EPI_F32_ACC
         float4* p = reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n);
         float4 o = *p;
@@ -199,9 +138,25 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
   }
 }
 
+// out (+)= sum over slabs (deterministic order); slabs are dense [M][N] fp32
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t slab, float* __restrict__ out, int M, int N,
+                                     int ldc, int acc) {
+  const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (idx >= (size_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  float4 s = *reinterpret_cast<const float4*>(ws + idx);
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + idx);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* p = reinterpret_cast<float4*>(out + (size_t)m * ldc + n);
+  if (acc) { const float4 o = *p; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+  *p = s;
+}
+
 template <int LAYOUT, int EPI>
-int launch_bk(const GemmArgs& a, int bk, hipStream_t s) {
-  const int grid = a.ntm * a.ntn;
+int launch_bk(const GemmArgs& a, int bk, int nsplit, hipStream_t s) {
+  const dim3 grid(a.ntm * a.ntn, nsplit);
   if (bk == 64) gemm_kernel<LAYOUT, EPI, 64><<<grid, NT_THREADS, 0, s>>>(a);
   else gemm_kernel<LAYOUT, EPI, 32><<<grid, NT_THREADS, 0, s>>>(a);
   CRL_LAUNCH_CHECK("crl_gemm_bf16");
@@ -209,14 +164,14 @@ int launch_bk(const GemmArgs& a, int bk, hipStream_t s) {
 }
 
 template <int LAYOUT>
-int launch_epi(const GemmArgs& a, int epi, int bk, hipStream_t s) {
+int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
   switch (epi) {
-    case CRL_EPI_BF16: return launch_bk<LAYOUT, CRL_EPI_BF16>(a, bk, s);
-    case CRL_EPI_BF16_GELU: return launch_bk<LAYOUT, CRL_EPI_BF16_GELU>(a, bk, s);
-    case CRL_EPI_BF16_DGELU: return launch_bk<LAYOUT, CRL_EPI_BF16_DGELU>(a, bk, s);
-    case CRL_EPI_F32_RESID: return launch_bk<LAYOUT, CRL_EPI_F32_RESID>(a, bk, s);
-    case CRL_EPI_F32: return launch_bk<LAYOUT, CRL_EPI_F32>(a, bk, s);
-    case CRL_EPI_F32_ACC: return launch_bk<LAYOUT, CRL_EPI_F32_ACC>(a, bk, s);
+    case CRL_EPI_BF16: return launch_bk<LAYOUT, CRL_EPI_BF16>(a, bk, nsplit, s);
+    case CRL_EPI_BF16_GELU: return launch_bk<LAYOUT, CRL_EPI_BF16_GELU>(a, bk, nsplit, s);
+    case CRL_EPI_BF16_DGELU: return launch_bk<LAYOUT, CRL_EPI_BF16_DGELU>(a, bk, nsplit, s);
+    case CRL_EPI_F32_RESID: return launch_bk<LAYOUT, CRL_EPI_F32_RESID>(a, bk, nsplit, s);
+    case CRL_EPI_F32: return launch_bk<LAYOUT, CRL_EPI_F32>(a, bk, nsplit, s);
+    case CRL_EPI_F32_ACC: return launch_bk<LAYOUT, CRL_EPI_F32_ACC>(a, bk, nsplit, s);
   }
   crl_set_error("crl_gemm_bf16: bad epilogue %d", epi);
   return -1;
@@ -224,10 +179,53 @@ int launch_epi(const GemmArgs& a, int epi, int bk, hipStream_t s) {
 
 }  // namespace
 
+int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
+
+// Kernel / split-K plan.  big = 256x256 8-phase kernel (one workgroup per CU) when it fills the chip, else the
+// 128x128 kernel.  The wgrad layout (few output tiles, very long contraction) cuts the contraction into nsplit
+// chunks: partial tiles go to fp32 slabs in the caller's scratch, then one deterministic reduce pass.
+struct Plan { bool big; int nsplit; int64_t chunk; };
+static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (tests)
+static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K, bool allow_split) {
+  Plan p{false, 1, 0};
+  const int64_t nk = (K + 63) / 64;
+  const bool splittable = allow_split && layout == CRL_TN && (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC) && nk >= 32;
+  const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool k64 = (layout == CRL_TN) || (K % 64) == 0;
+  auto split_for = [&](int64_t tiles, int64_t target) {
+    int ns = 1;
+    if (splittable && tiles < target) {
+      ns = (int)(target / tiles);
+      if (ns > 16) ns = 16;
+      while (ns > 1 && nk / ns < 8) --ns;
+    }
+    return ns < 1 ? 1 : ns;
+  };
+  if (k64 && g_policy != 1 && ((M >= 256 && N >= 256) || g_policy == 2)) {
+    const int ns = split_for(t256, 512);
+    if (t256 * ns >= 192 || g_policy == 2) { p.big = true; p.nsplit = ns; }
+  }
+  if (!p.big) p.nsplit = k64 ? split_for(t128, 768) : 1;
+  p.chunk = (nk + p.nsplit - 1) / p.nsplit;
+  p.nsplit = (int)((nk + p.chunk - 1) / p.chunk);
+  return p;
+}
+
+extern "C" int crl_gemm_set_policy(int policy) {
+  if (policy < 0 || policy > 2) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
+  g_policy = policy;
+  return 0;
+}
+
+extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
+  const Plan p = plan_gemm(layout, epilogue, M, N, K, true);
+  return p.nsplit > 1 ? (size_t)p.nsplit * M * N * sizeof(float) : 0;
+}
+
 extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                              const void* A, int64_t lda, const void* B, int64_t ldb,
                              const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
-                             const float* resid, int64_t ldr, void* stream) {
+                             const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream) {
   CRL_CHECK(M > 0 && N > 0 && K > 0, "crl_gemm_bf16: empty problem %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
   CRL_CHECK(A && B && C, "crl_gemm_bf16: null operand");
   CRL_CHECK((N % 4) == 0 && (ldc % 4) == 0, "crl_gemm_bf16: N (%lld) and ldc (%lld) must be multiples of 4", (long long)N, (long long)ldc);
@@ -257,9 +255,26 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   a.a_bytes = (uint32_t)ab; a.b_bytes = (uint32_t)bb;
   a.ntm = (int)((M + BM - 1) / BM); a.ntn = (int)((N + BN - 1) / BN);
   hipStream_t s = as_stream(stream);
+  Plan p = plan_gemm(layout, epilogue, M, N, K, ws != nullptr);
+  if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * M * N * sizeof(float)) p = plan_gemm(layout, epilogue, M, N, K, false);
+  if (bk == 32) { p.big = false; p.nsplit = 1; p.chunk = (K + 31) / 32; }
+  a.kchunk = (int)p.chunk;
+  a.slab_stride = 0;
+  if (p.big) { a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 255) / 256); }
+  if (p.nsplit > 1) {
+    GemmArgs b = a;
+    b.C = ws; b.ldc = (int)N; b.slab_stride = (size_t)M * N;
+    if (int rc = p.big ? crl_gemm256_launch(CRL_TN, CRL_EPI_F32, b, p.nsplit, s) : launch_epi<CRL_TN>(b, CRL_EPI_F32, bk, p.nsplit, s)) return rc;
+    const size_t n4 = (size_t)M * N / 4;
+    splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc,
+                                                                    epilogue == CRL_EPI_F32_ACC);
+    CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk reduce)");
+    return 0;
+  }
+  if (p.big) return crl_gemm256_launch(layout, epilogue, a, 1, s);
   switch (layout) {
-    case CRL_NT: return launch_epi<CRL_NT>(a, epilogue, bk, s);
-    case CRL_NN: return launch_epi<CRL_NN>(a, epilogue, bk, s);
-    default: return launch_epi<CRL_TN>(a, epilogue, bk, s);
+    case CRL_NT: return launch_epi<CRL_NT>(a, epilogue, bk, 1, s);
+    case CRL_NN: return launch_epi<CRL_NN>(a, epilogue, bk, 1, s);
+    default: return launch_epi<CRL_TN>(a, epilogue, bk, 1, s);
   }
 }

@@ -1,0 +1,258 @@
+// 256x256x64 bf16 MFMA GEMM, 8 waves, 8-phase software pipeline (guide §5 "256² 8-phase template"):
+// the large-shape path of crl_gemm_bf16 for all three layouts.
+//
+// Workgroup = 512 threads = 8 waves, one per CU (128 KiB LDS = 2 K-tile buffers x 4 half-tiles of
+// 16 KiB: A rows 0-127, B cols 0-127, B cols 128-255, A rows 128-255).  Wave (wr, wc) = (wave>>2, wave&3)
+// owns rows {64wr..+64} of BOTH A halves and cols {32wc..+32} of BOTH B halves, so quadrant
+// Q(qm, qn) of its 128x64 output uses exactly half-tile A[qm] and B[qn] for every wave -- half-tiles
+// are consumed in a fixed order (A0,B0 | B1 | A1 | -), which is what lets the LDS-DMA of later
+// K tiles land in a buffer one phase after its last read.
+//
+// Per K-tile, four phases of 16 MFMAs (one quadrant x K=64):
+//   phase 1: ds_read A0 (8 x b128) + B0 (4)   MFMA Q00      issue half-tile h+7
+//   phase 2: ds_read B1 (4)                   MFMA Q01      ...
+//   phase 3: ds_read A1 (8)                   MFMA Q11
+//   phase 4: (B0 kept in registers)           MFMA Q10      s_waitcnt vmcnt(6): all but the 3 youngest
+//                                                           half-tiles have landed -> next K-tile complete
+// Each phase: {ds_reads, 2 x buffer_load..lds, [vmcnt(6)], s_barrier, MFMA cluster, s_barrier}.
+// Hazards: RAW -- a buffer is read one phase after the vmcnt+barrier that retires its DMA;
+// WAR -- a half-tile is re-staged at least one full phase (two barriers) after its last ds_read, whose
+// data has been consumed by MFMAs before the closing barrier of that phase.
+#include <type_traits>
+#include "gemm_common.h"
+
+namespace {
+using namespace gemmc;
+
+constexpr int T256 = 512;
+#define BAR() asm volatile("s_barrier" ::: "memory")
+
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool A_TR = (LAYOUT == CRL_TN);
+  constexpr bool B_TR = (LAYOUT != CRL_NT);
+  constexpr int HT = 16384, BUF = 4 * HT;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = t / g.ntn, tn = t % g.ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const u32x4 ra = make_srd(g.A, g.a_bytes);
+  const u32x4 rb = make_srd(g.B, g.b_bytes);
+  const uint32_t smem_base = lds_addr_of(smem);
+
+  const int nk_all = (g.K + 63) / 64;
+  const int kt0 = blockIdx.y * g.kchunk;
+  const int nk = min(nk_all, kt0 + g.kchunk) - kt0;   // K tiles of this split
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS-DMA addressing: ONE per-thread byte offset per operand (VGPR) + a wave-uniform part (SGPR soffset) that
+  // carries the chunk, the half-tile and the K advance -- keeps the loop free of per-site address registers.
+  //   KM image chunk c = it*512 + tid: row = 64 it + (tid>>3), slot' = tid&7   (the swizzle does not depend on it)
+  //   TR image chunk c = it*512 + tid: krow = 32 it + (tid>>4), chunk' = tid&15
+  uint32_t voffA, voffB, stepA, stepB;   // stepX = byte distance between the two chunks a thread stages
+  if constexpr (A_TR) { const int kr = tid >> 4; voffA = (uint32_t)kr * g.lda * 2u + (uint32_t)(((tid & 15) ^ tr_swz(kr)) * 16); stepA = 32u * g.lda * 2u; }
+  else { const int r = tid >> 3; voffA = (uint32_t)r * g.lda * 2u + (uint32_t)(((tid & 7) ^ km_swz<64>(r)) * 16); stepA = 64u * g.lda * 2u; }
+  if constexpr (B_TR) { const int kr = tid >> 4; voffB = (uint32_t)kr * g.ldb * 2u + (uint32_t)(((tid & 15) ^ tr_swz(kr)) * 16); stepB = 32u * g.ldb * 2u; }
+  else { const int r = tid >> 3; voffB = (uint32_t)r * g.ldb * 2u + (uint32_t)(((tid & 7) ^ km_swz<64>(r)) * 16); stepB = 64u * g.ldb * 2u; }
+
+  // half-tile h (global sequence): K tile h>>2, slot j = h&3 : 0 = A0, 1 = B0, 2 = B1, 3 = A1
+  auto issue = [&](int tile, int j) {
+    const uint32_t lds = smem_base + (uint32_t)((tile & 1) * BUF + j * HT) + (uint32_t)wave * 1024u;
+    const uint32_t k0 = (uint32_t)(kt0 + tile) * 64u;
+    if (j == 0 || j == 3) {
+      const uint32_t r0 = (uint32_t)m0 + (j == 3 ? 128u : 0u);
+      const uint32_t soff = A_TR ? (k0 * g.lda + r0) * 2u : (r0 * g.lda + k0) * 2u;
+      dma16(ra, lds, voffA, soff);
+      dma16(ra, lds + 8192u, voffA, soff + stepA);
+    } else {
+      const uint32_t c0 = (uint32_t)n0 + (j == 2 ? 128u : 0u);
+      const uint32_t soff = B_TR ? (k0 * g.ldb + c0) * 2u : (c0 * g.ldb + k0) * 2u;
+      dma16(rb, lds, voffB, soff);
+      dma16(rb, lds + 8192u, voffB, soff + stepB);
+    }
+  };
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  auto readA = [&](int buf, int qm) {
+    const char* l = smem + buf * BUF + (qm ? 3 : 0) * HT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (A_TR) fa[i][ks] = frag_tr(l, 64 * wr + 16 * i, ks, lane);
+        else fa[i][ks] = frag_km<64>(l, 64 * wr + 16 * i, ks, lane);
+      }
+  };
+  auto readB = [&](int buf, int qn, bf16x8 (&f)[2][2]) {
+    const char* l = smem + buf * BUF + (qn ? 2 : 1) * HT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (B_TR) f[j][ks] = frag_tr(l, 32 * wc + 16 * j, ks, lane);
+        else f[j][ks] = frag_km<64>(l, 32 * wc + 16 * j, ks, lane);
+      }
+  };
+  auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&b)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[i][j]) : "v"(b[j][ks]), "v"(fa[i][ks]));
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: half-tiles 0..6 in flight, first K tile (0..3) landed
+  issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+  issue(1, 0); issue(1, 1); issue(1, 2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  BAR();
+
+  // four phases of one K tile held in LDS buffer BUFI; `te` = index of the even tile of the current pair
+  auto tile_phases = [&](auto bufc, int t_issue_a, int t_issue_b) {
+    constexpr int BUFI = decltype(bufc)::value;
+    // phase 1 / 5
+    readA(BUFI, 0); readB(BUFI, 0, fb0);
+    issue(t_issue_a, 3);
+    BAR();
+    mma(acc[0][0], fb0);
+    BAR();
+    // phase 2 / 6
+    readB(BUFI, 1, fb1);
+    issue(t_issue_b, 0);
+    BAR();
+    mma(acc[0][1], fb1);
+    BAR();
+    // phase 3 / 7
+    readA(BUFI, 1);
+    issue(t_issue_b, 1);
+    BAR();
+    mma(acc[1][1], fb1);
+    BAR();
+    // phase 4 / 8
+    issue(t_issue_b, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    BAR();
+    mma(acc[1][0], fb0);
+    BAR();
+  };
+  const int npairs = nk >> 1;
+#pragma nounroll
+  for (int it = 0; it < npairs; ++it) {
+    const int te = 2 * it;      // even K tile -> buffer 0, odd -> buffer 1
+    tile_phases(std::integral_constant<int, 0>{}, te + 1, te + 2);
+    tile_phases(std::integral_constant<int, 1>{}, te + 2, te + 3);
+  }
+  if (nk & 1) tile_phases(std::integral_constant<int, 0>{}, nk, nk + 1);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
+
+  // ---------------- epilogue: lane (li, lq) holds C[m = .. + li][n = .. + 4 lq + 0..3]
+  // opaque copies: nothing of the epilogue's address arithmetic may be hoisted above the K loop (it would sit in
+  // ~80 VGPRs across the loop and push the accumulators into scratch)
+  int lane_e = lane, m0e = m0, n0e = n0;
+  asm volatile("" : "+v"(lane_e), "+s"(m0e), "+s"(n0e));
+  const int li = lane_e & 15, lq = lane_e >> 4;
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0e + 128 * qm + 64 * wr + 16 * i + li;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0e + 128 * qn + 32 * wc + 16 * j + 4 * lq;
+          if (n >= g.N) continue;
+          const f32x4 a4 = acc[qm][qn][i][j];
+          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+          if constexpr (EPI == CRL_EPI_BF16 || EPI == CRL_EPI_BF16_GELU || EPI == CRL_EPI_F32_RESID) {
+            if (g.bias) {
+              const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+              v[0] += round_bf(b.x); v[1] += round_bf(b.y); v[2] += round_bf(b.z); v[3] += round_bf(b.w);
+            }
+          }
+          if constexpr (EPI == CRL_EPI_BF16) {
+            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
+            float h[4], y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
+            *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+          } else if constexpr (EPI == CRL_EPI_BF16_DGELU) {
+            const uint2 hh = *reinterpret_cast<const uint2*>((const u16*)g.aux + (size_t)m * g.ldaux + n);
+            const float h0 = bf2f(hh.x & 0xffff), h1 = bf2f(hh.x >> 16), h2 = bf2f(hh.y & 0xffff), h3 = bf2f(hh.y >> 16);
+            const float y0 = round_bf(v[0]) * dgelu_f(h0), y1 = round_bf(v[1]) * dgelu_f(h1);
+            const float y2 = round_bf(v[2]) * dgelu_f(h2), y3 = round_bf(v[3]) * dgelu_f(h3);
+            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y0, y1), pack_bf2(y2, y3)};
+          } else if constexpr (EPI == CRL_EPI_F32_RESID) {
+            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+            *reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n) =
+                float4{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
+          } else if constexpr (EPI == CRL_EPI_F32) {
+            *reinterpret_cast<float4*>((float*)g.C + blockIdx.y * g.slab_stride + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
+          } else {
+            float4* p = reinterpret_cast<float4*>((float*)g.C + (size_t)m * g.ldc + n);
+            float4 o = *p;
+            o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+            *p = o;
+          }
+        }
+    }
+}
+
+template <int LAYOUT, int EPI>
+int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<LAYOUT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (e != hipSuccess) { crl_set_error("gemm256: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -2; }
+    configured = true;
+  }
+  gemm256_kernel<LAYOUT, EPI><<<dim3(a.ntm * a.ntn, nsplit), T256, 131072, s>>>(a);
+  CRL_LAUNCH_CHECK("crl_gemm_bf16(256)");
+  return 0;
+}
+
+template <int LAYOUT>
+int launch256_epi(const GemmArgs& a, int epi, int nsplit, hipStream_t s) {
+  switch (epi) {
+    case CRL_EPI_BF16: return launch256_one<LAYOUT, CRL_EPI_BF16>(a, nsplit, s);
+    case CRL_EPI_BF16_GELU: return launch256_one<LAYOUT, CRL_EPI_BF16_GELU>(a, nsplit, s);
+    case CRL_EPI_BF16_DGELU: return launch256_one<LAYOUT, CRL_EPI_BF16_DGELU>(a, nsplit, s);
+    case CRL_EPI_F32_RESID: return launch256_one<LAYOUT, CRL_EPI_F32_RESID>(a, nsplit, s);
+    case CRL_EPI_F32: return launch256_one<LAYOUT, CRL_EPI_F32>(a, nsplit, s);
+    case CRL_EPI_F32_ACC: return launch256_one<LAYOUT, CRL_EPI_F32_ACC>(a, nsplit, s);
+  }
+  crl_set_error("crl_gemm_bf16: bad epilogue %d", epi);
+  return -1;
+}
+
+}  // namespace
+
+// called by crl_gemm_bf16 (gemm.hip) for shapes where the big tile pays
+int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
+  switch (layout) {
+    case CRL_NT: return launch256_epi<CRL_NT>(a, epi, nsplit, s);
+    case CRL_NN: return launch256_epi<CRL_NN>(a, epi, nsplit, s);
+    default: return launch256_epi<CRL_TN>(a, epi, nsplit, s);
+  }
+}

@@ -1,0 +1,78 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: 128x128 tiles, gemm256.hip: 256x256 8-phase):
+// argument block, LDS images + swizzles, LDS-DMA staging and fragment reads.
+#pragma once
+#include "common.h"
+
+namespace gemmc {
+
+
+struct GemmArgs {
+  const u16* A; const u16* B; const float* bias; void* C; void* aux; const float* resid;
+  int M, N, K;
+  int lda, ldb, ldc, ldaux, ldr;
+  uint32_t a_bytes, b_bytes;
+  int ntm, ntn;
+  int kchunk;            // K tiles per split (gridDim.y splits; split s writes slab s of C)
+  size_t slab_stride;    // elements between slabs
+};
+
+// ---- swizzles (see the bank analysis in DESIGN.md "GEMM LDS images") ----
+template <int BK> __device__ __forceinline__ int km_swz(int row) {
+  return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+__device__ __forceinline__ int tr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// Issue the LDS-DMA for one operand tile.  KM: tile rows = matrix rows r0.., k contiguous from k0.
+template <int BK, int NTHR>
+__device__ __forceinline__ void stage_km(__amdgpu_buffer_rsrc_t rs, char* lds, int r0, int k0, int ld,
+                                         int tid, int wave) {
+  constexpr int CPR = BK / 8;                   // 16-B chunks per row
+  constexpr int NCH = 128 * CPR / NTHR;   // chunks per thread
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = it * NTHR + tid;
+    const int row = c / CPR, ps = c % CPR;
+    const int ls = ps ^ km_swz<BK>(row);
+    const uint32_t off = ((uint32_t)(r0 + row) * (uint32_t)ld + (uint32_t)(k0 + ls * 8)) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NTHR + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+// TR: tile rows = contraction index k0.., columns c0.. of the matrix (128 of them).
+template <int BK, int NTHR>
+__device__ __forceinline__ void stage_tr(__amdgpu_buffer_rsrc_t rs, char* lds, int k0, int c0, int ld,
+                                         int tid, int wave) {
+  constexpr int NCH = BK * 16 / NTHR;
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = it * NTHR + tid;
+    const int row = c >> 4, pc = c & 15;
+    const int lc = pc ^ tr_swz(row);
+    const uint32_t off = ((uint32_t)(k0 + row) * (uint32_t)ld + (uint32_t)(c0 + lc * 8)) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NTHR + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+
+// fragment (8 bf16 along k) for the 16 rows/cols [base, base+16) of a staged tile, k-step ks
+template <int BK>
+__device__ __forceinline__ bf16x8 frag_km(const char* lds, int base, int ks, int lane) {
+  const int row = base + (lane & 15), g = lane >> 4;
+  const int slot = ks * 4 + g;
+  const int addr = row * (BK * 2) + ((slot ^ km_swz<BK>(row)) << 4);
+  return *reinterpret_cast<const bf16x8*>(lds + addr);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int base, int ks, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = base + 4 * p;
+  const int k1 = ks * 32 + 8 * g + q;
+  const int a1 = k1 * 256 + ((((col >> 3)) ^ tr_swz(k1)) << 4) + (col & 7) * 2;
+  const int k2 = k1 + 4;
+  const int a2 = k2 * 256 + ((((col >> 3)) ^ tr_swz(k2)) << 4) + (col & 7) * 2;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a1));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a2));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);
+}
+
+
+}  // namespace gemmc

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
     from pixparse_amd import hip
     hip.load()
     with pytest.raises(hip.HipLibraryError, match='multiple of 32'):
-        hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, None)
+        hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, None, 0, None)
     with pytest.raises(hip.HipLibraryError, match='empty'):
         hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, None)
     with pytest.raises(hip.HipLibraryError, match='window'):

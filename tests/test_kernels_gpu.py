@@ -112,6 +112,60 @@ def test_gemm_strided_views_and_errors(dev):
         ops.linear_fwd(rnd((8, 40), dev, 1, 1, BF16), rnd((8, 40), dev, 1, 2, BF16), None, torch.empty(8, 8, dtype=BF16, device=dev))  # K % 32
 
 
+@pytest.mark.parametrize('K', [64, 128, 192, 448])
+def test_gemm_256_kernel_all_layouts(dev, K):
+    """the 256x256 8-phase kernel forced on ragged shapes (odd / even / single K-tile counts), against the 128 kernel's
+    reference math; then the split-K wgrad path through fp32 slabs"""
+    from pixparse_amd import hip, ops
+    M, N = 600, 520
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    dy = rnd((M, N), dev, 1.0, 4, BF16)
+    hip.call('crl_gemm_set_policy', 2)
+    try:
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        pre = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out, ops.EPI_BF16_GELU, aux=pre)
+        ref = x.float() @ w.float().t() + bias.to(BF16).float()
+        close(pre, ref, 1e-2, 1e-2, '256 NT aux')
+        close(out, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, '256 NT gelu')
+        y = rnd((M, N), dev, 1.0, 5)
+        want = y + ref.to(BF16).float()
+        ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+        close(y, want, 1e-2, 2e-2, '256 NT resid')
+        if N % 32 == 8:                       # NN needs the contraction (N) to be a multiple of 32: use the first 512 columns
+            dyc, wc = dy[:, :512], w[:512]
+            dx = torch.empty(M, K, dtype=BF16, device=dev)
+            ops.linear_dgrad(dyc, wc, dx)
+            close(dx, dyc.float() @ wc.float(), 1e-2, 2e-2, '256 NN')
+        dw = torch.full((N, K), 3.0, device=dev)
+        ops.linear_wgrad(dy, x, dw, accumulate=True)
+        close(dw, 3.0 + dy.float().t() @ x.float(), 2e-3, 5e-2, '256 TN acc')
+    finally:
+        hip.call('crl_gemm_set_policy', 0)
+
+
+def test_gemm_256_splitk_wgrad(dev):
+    from pixparse_amd import hip, ops
+    Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
+    dy = rnd((Mrows, N), dev, 1.0, 1, BF16)
+    x = rnd((Mrows, K), dev, 1.0, 2, BF16)
+    ref = dy.float().t() @ x.float()
+    for policy in (2, 1, 0):
+        hip.call('crl_gemm_set_policy', policy)
+        try:
+            assert hip.query('crl_gemm_ws_bytes', hip.TN, hip.EPI_F32_ACC, N, K, Mrows) > 0
+            dw = torch.full((N, K), 1.0, device=dev)
+            ops.linear_wgrad(dy, x, dw, accumulate=True)
+            close(dw, 1.0 + ref, 2e-3, 0.2, f'split-K wgrad policy {policy}')
+            dw2 = torch.full((N, K), 1.0, device=dev)
+            ops.linear_wgrad(dy, x, dw2, accumulate=True)
+            assert torch.equal(dw, dw2), 'slab reduction must be deterministic'
+        finally:
+            hip.call('crl_gemm_set_policy', 0)
+
+
 # ------------------------------------------------------------------------------------------- LayerNorm & row ops
 @pytest.mark.parametrize('M,D', [(37, 96), (1001, 1024), (5, 1536)])
 def test_layernorm(dev, M, D):
