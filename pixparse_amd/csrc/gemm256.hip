@@ -45,6 +45,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   const u32x4 ra = make_srd(g.A, g.a_bytes);
   const u32x4 rb = make_srd(g.B, g.b_bytes);
   const uint32_t smem_base = lds_addr_of(smem);
+  const u32x4 rzero = make_srd(g.A, 0);   // zero records: every load through it returns zeros (K tiles past the end)
 
   const int nk_all = (g.K + 63) / 64;
   const int kt0 = blockIdx.y * g.kchunk;
@@ -74,16 +75,19 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   auto issue = [&](int tile, int j) {
     const uint32_t lds = smem_base + (uint32_t)((tile & 1) * BUF + j * HT) + (uint32_t)wave * 1024u;
     const uint32_t k0 = (uint32_t)(kt0 + tile) * 64u;
+    const bool live = tile < nk;          // tiles past this split's range contribute zeros (odd tile counts, pipeline tail)
     if (j == 0 || j == 3) {
       const uint32_t r0 = (uint32_t)m0 + (j == 3 ? 128u : 0u);
       const uint32_t soff = A_TR ? (k0 * g.lda + r0) * 2u : (r0 * g.lda + k0) * 2u;
-      dma16(ra, lds, voffA, soff);
-      dma16(ra, lds + 8192u, voffA, soff + stepA);
+      const u32x4 r = live ? ra : rzero;
+      dma16(r, lds, voffA, soff);
+      dma16(r, lds + 8192u, voffA, soff + stepA);
     } else {
       const uint32_t c0 = (uint32_t)n0 + (j == 2 ? 128u : 0u);
       const uint32_t soff = B_TR ? (k0 * g.ldb + c0) * 2u : (c0 * g.ldb + k0) * 2u;
-      dma16(rb, lds, voffB, soff);
-      dma16(rb, lds + 8192u, voffB, soff + stepB);
+      const u32x4 r = live ? rb : rzero;
+      dma16(r, lds, voffB, soff);
+      dma16(r, lds + 8192u, voffB, soff + stepB);
     }
   };
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
@@ -118,48 +122,55 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // prologue: half-tiles 0..6 in flight, first K tile (0..3) landed
+  // prologue: half-tiles 0..5 in flight, first K tile (0..3) landed
   issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-  issue(1, 0); issue(1, 1); issue(1, 2);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  issue(1, 0); issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   BAR();
+  // stagger (guide §5 template): the wr==1 waves run one barrier behind, so on every SIMD one wave is in its
+  // MFMA cluster while its partner (the wave 4 slots away shares the SIMD) issues LDS reads and DMA.
+  if (wr == 1) BAR();
 
-  // four phases of one K tile held in LDS buffer BUFI; `te` = index of the even tile of the current pair
-  auto tile_phases = [&](auto bufc, int t_issue_a, int t_issue_b) {
+  // four phases of the K tile in LDS buffer BUFI.  Half-tile sequence h = 4*tile + j (j: A0,B0,B1,A1); the phase
+  // p of tile t issues h = 4t + 5 + p, i.e. (t+1,B1) (t+1,A1) (t+2,A0) (t+2,B0): every slot is re-staged >= 2 phases
+  // after its last ds_read (A0: ph1 -> ph3, B0: ph1 -> ph4, B1: ph2 -> next ph1, A1: ph3 -> next ph2).
+  auto tile_phases = [&](auto bufc, int t1, int t2) {
     constexpr int BUFI = decltype(bufc)::value;
-    // phase 1 / 5
+    // phase 1
     readA(BUFI, 0); readB(BUFI, 0, fb0);
-    issue(t_issue_a, 3);
+    issue(t1, 2);
     BAR();
     mma(acc[0][0], fb0);
     BAR();
-    // phase 2 / 6
+    // phase 2
     readB(BUFI, 1, fb1);
-    issue(t_issue_b, 0);
+    issue(t1, 3);
     BAR();
     mma(acc[0][1], fb1);
     BAR();
-    // phase 3 / 7
+    // phase 3
     readA(BUFI, 1);
-    issue(t_issue_b, 1);
+    issue(t2, 0);
     BAR();
     mma(acc[1][1], fb1);
     BAR();
-    // phase 4 / 8
-    issue(t_issue_b, 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // phase 4: all but the two youngest half-tiles landed -> K tile t1 is complete for the next four phases
+    issue(t2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     BAR();
     mma(acc[1][0], fb0);
     BAR();
+    // hipcc does not model the asm MFMAs: settle the XDL pipe before anything it may place at the loop boundary
+    asm volatile("s_nop 7" ::: "memory");
   };
-  const int npairs = nk >> 1;
+  const int npairs = (nk + 1) >> 1;   // an odd tile count is padded with one all-zero K tile
 #pragma nounroll
   for (int it = 0; it < npairs; ++it) {
     const int te = 2 * it;      // even K tile -> buffer 0, odd -> buffer 1
     tile_phases(std::integral_constant<int, 0>{}, te + 1, te + 2);
     tile_phases(std::integral_constant<int, 1>{}, te + 2, te + 3);
   }
-  if (nk & 1) tile_phases(std::integral_constant<int, 0>{}, nk, nk + 1);
+  if (wr == 0) BAR();
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
 
   // ---------------- epilogue: lane (li, lq) holds C[m = .. + li][n = .. + 4 lq + 0..3]
