@@ -15,6 +15,7 @@
 // Tiles of 64 rows x 64 bf16 (128-B rows) are staged by bounds-checked LDS-DMA (rows past the end
 // of the sequence arrive as zeros) with one XOR swizzle that is conflict-free for BOTH the
 // ds_read_b128 row reads and the transposed reads.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -37,36 +38,71 @@ __device__ __forceinline__ int swz64(int row) {
   return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
 }
 
-// stage 64 rows x 64 bf16 starting at row `row0` of a [*, rs]-strided matrix into an 8-KB LDS tile
-__device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs_, char* lds, int row0, int64_t rs, int tid, int wave) {
+// Per-lane LDS byte offsets (tile base 0) of every fragment read, computed ONCE before the tile loop and made
+// opaque so hipcc keeps them in registers instead of re-deriving ~100 integer ops per tile; tile / block bases are
+// compile-time constants that fold into the ds_read offset field.
+struct LaneAddr {
+  uint32_t row[4];     // frag_row: [ks], rows 0..31 (+4096 B for rows 32..63)
+  uint32_t tr[2][2];   // frag_tr: [db][first / second 4-row group], kbase 0 (+128*kbase B)
+};
+__device__ __forceinline__ LaneAddr make_lane_addr(int lane) {
+  LaneAddr la;
+  const int row = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int c = it * 256 + tid;
-    const int row = c >> 3, pc = c & 7;
-    const int lc = pc ^ swz64(row);
-    const uint32_t off = (uint32_t)(((int64_t)(row0 + row) * rs + lc * 8) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, LDS_PTR(lds + (it * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+  for (int ks = 0; ks < 4; ++ks) la.row[ks] = (uint32_t)(row * 128 + (((2 * ks + hh) ^ swz64(row)) << 4));
+  const int G = lane >> 4, idx = lane & 15, qq = idx >> 2, p = idx & 3;
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int col = 32 * db + 16 * (G & 1) + 4 * p;
+    const int r1 = 4 * hh + qq, r2 = r1 + 8;
+    la.tr[db][0] = (uint32_t)(r1 * 128 + (((col >> 3) ^ swz64(r1)) << 4) + (col & 7) * 2);
+    la.tr[db][1] = (uint32_t)(r2 * 128 + (((col >> 3) ^ swz64(r2)) << 4) + (col & 7) * 2);
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(la.row[i]));
+  asm volatile("" : "+v"(la.tr[0][0]), "+v"(la.tr[0][1]), "+v"(la.tr[1][0]), "+v"(la.tr[1][1]));
+  return la;
 }
 // MFMA 32x32x16 operand whose k index is contiguous in the tile row: rows rowbase..+31, k = 16ks + 8h + j
-__device__ __forceinline__ bf16x8 frag_row(const char* lds, int rowbase, int ks, int lane) {
-  const int row = rowbase + (lane & 31);
-  const int chunk = 2 * ks + (lane >> 5);
-  return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ swz64(row)) << 4));
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, const LaneAddr& la, int rowbase, int ks) {
+  return *reinterpret_cast<const bf16x8*>(tile + la.row[ks] + rowbase * 128);
 }
 // MFMA 32x32x16 operand whose k index is the tile ROW: operand row = tile column 32db + (lane&31),
 // element j of lane half h = tile row kbase + 8(j>>2) + 4h + (j&3)  (the accumulator k order)
-__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int kbase, int db, int lane) {
-  const int G = lane >> 4, idx = lane & 15, qq = idx >> 2, p = idx & 3, hh = lane >> 5;
-  const int col = 32 * db + 16 * (G & 1) + 4 * p;
-  const int r1 = kbase + 4 * hh + qq, r2 = r1 + 8;
-  const int a1 = r1 * 128 + (((col >> 3) ^ swz64(r1)) << 4) + (col & 7) * 2;
-  const int a2 = r2 * 128 + (((col >> 3) ^ swz64(r2)) << 4) + (col & 7) * 2;
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a1));
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds + a2));
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, const LaneAddr& la, int kbase, int db) {
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + la.tr[db][0] + kbase * 128));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + la.tr[db][1] + kbase * 128));
   typedef short short8v __attribute__((ext_vector_type(8)));
   const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, both);
+}
+// LDS-DMA staging of a 64-row x 64-bf16 tile: per-thread source offset (swizzled chunk of row tid>>3, rows +32 for
+// the second chunk) in a VGPR, everything wave-uniform in the scalar offset.
+struct StageOff { uint32_t v; };
+__device__ __forceinline__ StageOff make_stage_off(int tid, int64_t rs) {
+  const int row = tid >> 3, pc = tid & 7;
+  StageOff s{(uint32_t)(((int64_t)row * rs + ((pc ^ swz64(row)) * 8)) * 2)};
+  asm volatile("" : "+v"(s.v));
+  return s;
+}
+__device__ __forceinline__ void stage64(u32x4 srd, uint32_t lds_tile, StageOff so, int row0, int64_t rs, int wave) {
+  const uint32_t soff = (uint32_t)((int64_t)row0 * rs * 2);
+  dma16(srd, lds_tile + (uint32_t)wave * 1024u, so.v, soff);
+  dma16(srd, lds_tile + 4096u + (uint32_t)wave * 1024u, so.v, soff + (uint32_t)(32 * rs * 2));
+}
+__device__ __forceinline__ void dma4(u32x4 srd, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// value held by lane ^ 32
+__device__ __forceinline__ float swap32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
 // registers 8s..8s+7 of a 32x32 accumulator as the next product's operand
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
@@ -99,6 +135,8 @@ __device__ __forceinline__ void block_to_bh_tile(int bid, int ntile, int BH, int
 }
 
 // ======================================================================================= forward
+template <int V> using ic = std::integral_constant<int, V>;
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
@@ -111,10 +149,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   const int off = a.Nk - a.Nq;
 
   const u16* qp = a.q + b * a.q_bs + h * 64;
-  const u16* kp = a.k + b * a.k_bs + h * 64;
-  const u16* vp = a.v + b * a.v_bs + h * 64;
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kp, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vp, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const u32x4 rk = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const uint32_t sbase = lds_addr_of(smem);
+  const LaneAddr la = make_lane_addr(lane);
+  const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
 
   const int q0 = qt * 128 + wave * 32;
   const int qrow = min(q0 + qi, a.Nq - 1);
@@ -131,23 +170,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   const float c = a.scale * LOG2E;
   const int qabs = q0 + qi;
 
-  if (nt > 0) { stage64(rk, smem, 0, a.k_rs, tid, wave); stage64(rv, smem + 8192, 0, a.v_rs, tid, wave); }
-  for (int kt = 0; kt < nt; ++kt) {
+  auto stage = [&](int buf, int kt) {
+    stage64(rk, sbase + buf * 16384, sk, kt * 64, a.k_rs, wave);
+    stage64(rv, sbase + buf * 16384 + 8192, sv, kt * 64, a.v_rs, wave);
+  };
+  auto tile = [&](auto bufc, int kt) {
+    constexpr int BUFI = decltype(bufc)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int buf = kt & 1;
-    if (kt + 1 < nt) {
-      stage64(rk, smem + (buf ^ 1) * 16384, (kt + 1) * 64, a.k_rs, tid, wave);
-      stage64(rv, smem + (buf ^ 1) * 16384 + 8192, (kt + 1) * 64, a.v_rs, tid, wave);
-    }
-    const char* kl = smem + buf * 16384;
+    if (kt + 1 < nt) stage(BUFI ^ 1, kt + 1);
+    const char* kl = smem + BUFI * 16384;
     const char* vl = kl + 8192;
     const int k0 = kt * 64;
     f32x16 s0 = zero16(), s1 = zero16();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s0 = mfma32(frag_row(kl, 0, ks, lane), qf[ks], s0);
-      s1 = mfma32(frag_row(kl, 32, ks, lane), qf[ks], s1);
+      s0 = mfma32(frag_row(kl, la, 0, ks), qf[ks], s0);
+      s1 = mfma32(frag_row(kl, la, 32, ks), qf[ks], s1);
     }
     // ---- online softmax, query on the lane, this lane holds 2 x 16 of the tile's 64 keys
     const bool need_mask = (k0 + 64 > a.Nk) || (CAUSAL && (k0 + 63 > q0 + off));
@@ -160,14 +199,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         if (key + 32 > lim) s1[r] = -INFINITY;
       }
     }
-    float mx = -INFINITY;
+    // row max: 16 x v_max3_f32 (plain fmaxf makes hipcc canonicalise every MFMA output with an extra v_max), then
+    // one v_permlane32_swap to combine the two lane halves that share a query
+    float mx = max3f(s0[0], s1[0], -INFINITY);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    for (int r = 1; r < 16; ++r) mx = max3f(mx, s0[r], s1[r]);
+    mx = max3f(mx, swap32(mx), -INFINITY);
     const float m_new = fmaxf(m, mx * c);          // scores scaled into the log2 domain (c > 0)
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
-    m = m_new;
+    if (__any(m_new != m)) {                       // wave-uniform: most tiles leave every running max untouched
+      const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+      l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m = m_new;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -175,20 +221,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
       s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -m_use));
       ps += s0[r] + s1[r];
     }
-    l = l * alpha + ps;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    l += ps;
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8 p0 = acc_frag(s0, s), p1 = acc_frag(s1, s);
-      o0 = mfma32(frag_tr(vl, 16 * s, 0, lane), p0, o0);
-      o1 = mfma32(frag_tr(vl, 16 * s, 1, lane), p0, o1);
-      o0 = mfma32(frag_tr(vl, 32 + 16 * s, 0, lane), p1, o0);
-      o1 = mfma32(frag_tr(vl, 32 + 16 * s, 1, lane), p1, o1);
+      o0 = mfma32(frag_tr(vl, la, 16 * s, 0), p0, o0);
+      o1 = mfma32(frag_tr(vl, la, 16 * s, 1), p0, o1);
+      o0 = mfma32(frag_tr(vl, la, 32 + 16 * s, 0), p1, o0);
+      o1 = mfma32(frag_tr(vl, la, 32 + 16 * s, 1), p1, o1);
     }
+  };
+  if (nt > 0) stage(0, 0);
+  for (int kt = 0; kt < nt; kt += 2) {
+    tile(ic<0>{}, kt);
+    if (kt + 1 < nt) tile(ic<1>{}, kt + 1);
   }
-  l += __shfl_xor(l, 32, 64);
+  l += swap32(l);
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (qabs < a.Nq) {
     u16* op = a.out + b * a.o_bs + (int64_t)qabs * a.o_rs + h * 64;
@@ -227,8 +276,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // workgroup = 128 keys of one (b,h) (32 per wave, K/V fragments in registers), sweeps query tiles of 64.
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (2 * 8192 + 512)];  // [buf][Q | dO | lse*log2e(64) | delta(64)]
-  constexpr int BUF = 2 * 8192 + 512;
+  constexpr int BUF = 2 * 8192 + 512;  // [Q | dO | lse(64 f32) | delta(64 f32)]
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ki = lane & 31, hh = lane >> 5;
@@ -237,12 +286,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
   const int b = bh / a.H, h = bh % a.H;
   const int off = a.Nk - a.Nq;
 
-  const u16* qp = a.q + b * a.q_bs + h * 64;
-  const u16* dop = a.d_o + b * a.do_bs + h * 64;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qp, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dop, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
-  const float* lsep = a.lse + ((int64_t)b * a.H + h) * a.Nq;
-  const float* delp = a.delta + ((int64_t)b * a.H + h) * a.Nq;
+  const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
+  const u32x4 rdo = make_srd(a.d_o + b * a.do_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
+  const u32x4 rl = make_srd(a.lse + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);
+  const u32x4 rd = make_srd(a.delta + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);
+  const uint32_t sbase = lds_addr_of(smem);
+  const LaneAddr la = make_lane_addr(lane);
+  const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs);
 
   const int key0 = ktile * 128 + wave * 32;
   const int kabs = key0 + ki;
@@ -261,24 +311,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
   const float c = a.scale * LOG2E;
 
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(lsep, (uint32_t)a.Nq * 4u);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(delp, (uint32_t)a.Nq * 4u);
   auto stage = [&](int buf, int t) {
-    char* base = smem + buf * BUF;
-    stage64(rq, base, t * 64, a.q_rs, tid, wave);
-    stage64(rdo, base + 8192, t * 64, a.do_rs, tid, wave);
+    const uint32_t base = sbase + buf * BUF;
+    stage64(rq, base, sq, t * 64, a.q_rs, wave);
+    stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
     // 64 lse + 64 delta values of the tile by 4-byte LDS-DMA (rows past Nq arrive as 0; their Q and dO rows are 0 too)
-    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, LDS_PTR(base + 16384), 4, (uint32_t)(t * 64 + lane) * 4u, 0, 0, 0);
-    else if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(base + 16384 + 256), 4, (uint32_t)(t * 64 + lane) * 4u, 0, 0, 0);
+    if (wave == 0) dma4(rl, base + 16384, (uint32_t)lane * 4u, (uint32_t)t * 256u);
+    else if (wave == 1) dma4(rd, base + 16384 + 256, (uint32_t)lane * 4u, (uint32_t)t * 256u);
   };
-
-  if (qstart_tile < nqt64) stage(0, qstart_tile);
-  for (int t = qstart_tile; t < nqt64; ++t) {
+  auto tile = [&](auto bufc, int t) {
+    constexpr int BUFI = decltype(bufc)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int buf = (t - qstart_tile) & 1;
-    if (t + 1 < nqt64) stage(buf ^ 1, t + 1);
-    const char* ql = smem + buf * BUF;
+    if (t + 1 < nqt64) stage(BUFI ^ 1, t + 1);
+    const char* ql = smem + BUFI * BUF;
     const char* dol = ql + 8192;
     const float* lse_s = reinterpret_cast<const float*>(ql + 16384);
     const float* del_s = lse_s + 64;
@@ -287,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(ql, 32 * qb, ks, lane), kf[ks], s);
-        dp = mfma32(frag_row(dol, 32 * qb, ks, lane), vf[ks], dp);
+        s = mfma32(frag_row(ql, la, 32 * qb, ks), kf[ks], s);
+        dp = mfma32(frag_row(dol, la, 32 * qb, ks), vf[ks], dp);
       }
       const int qbase = t * 64 + 32 * qb;
       const bool need_mask = CAUSAL && (key0 + 31 > qbase + off);
@@ -309,12 +355,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 pf = acc_frag(s, ss), dsf = acc_frag(dp, ss);
-        dv0 = mfma32(frag_tr(dol, 32 * qb + 16 * ss, 0, lane), pf, dv0);
-        dv1 = mfma32(frag_tr(dol, 32 * qb + 16 * ss, 1, lane), pf, dv1);
-        dk0 = mfma32(frag_tr(ql, 32 * qb + 16 * ss, 0, lane), dsf, dk0);
-        dk1 = mfma32(frag_tr(ql, 32 * qb + 16 * ss, 1, lane), dsf, dk1);
+        dv0 = mfma32(frag_tr(dol, la, 32 * qb + 16 * ss, 0), pf, dv0);
+        dv1 = mfma32(frag_tr(dol, la, 32 * qb + 16 * ss, 1), pf, dv1);
+        dk0 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 0), dsf, dk0);
+        dk1 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 1), dsf, dk1);
       }
     }
+  };
+  if (qstart_tile < nqt64) stage(0, qstart_tile);
+  for (int t = qstart_tile; t < nqt64; t += 2) {
+    tile(ic<0>{}, t);
+    if (t + 1 < nqt64) tile(ic<1>{}, t + 1);
   }
   if (kabs < a.Nk) {
     u16* dkp = a.dk + b * a.dk_bs + (int64_t)kabs * a.dk_rs + h * 64;
@@ -344,10 +395,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   const int b = bh / a.H, h = bh % a.H;
   const int off = a.Nk - a.Nq;
 
-  const u16* kp = a.k + b * a.k_bs + h * 64;
-  const u16* vp = a.v + b * a.v_bs + h * 64;
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kp, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vp, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const u32x4 rk = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const uint32_t sbase = lds_addr_of(smem);
+  const LaneAddr la = make_lane_addr(lane);
+  const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
 
   const int q0 = qt * 128 + wave * 32;
   const int qabs = q0 + qi;
@@ -367,16 +419,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   f32x16 dq0 = zero16(), dq1 = zero16();
   const float c = a.scale * LOG2E;
 
-  if (nt > 0) { stage64(rk, smem, 0, a.k_rs, tid, wave); stage64(rv, smem + 8192, 0, a.v_rs, tid, wave); }
-  for (int kt = 0; kt < nt; ++kt) {
+  auto stage = [&](int buf, int kt) {
+    stage64(rk, sbase + buf * 16384, sk, kt * 64, a.k_rs, wave);
+    stage64(rv, sbase + buf * 16384 + 8192, sv, kt * 64, a.v_rs, wave);
+  };
+  auto tile = [&](auto bufc, int kt) {
+    constexpr int BUFI = decltype(bufc)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int buf = kt & 1;
-    if (kt + 1 < nt) {
-      stage64(rk, smem + (buf ^ 1) * 16384, (kt + 1) * 64, a.k_rs, tid, wave);
-      stage64(rv, smem + (buf ^ 1) * 16384 + 8192, (kt + 1) * 64, a.v_rs, tid, wave);
-    }
-    const char* kl = smem + buf * 16384;
+    if (kt + 1 < nt) stage(BUFI ^ 1, kt + 1);
+    const char* kl = smem + BUFI * 16384;
     const char* vl = kl + 8192;
     const int k0 = kt * 64;
 #pragma unroll
@@ -384,8 +436,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(kl, 32 * kb, ks, lane), qf[ks], s);
-        dp = mfma32(frag_row(vl, 32 * kb, ks, lane), dof[ks], dp);
+        s = mfma32(frag_row(kl, la, 32 * kb, ks), qf[ks], s);
+        dp = mfma32(frag_row(vl, la, 32 * kb, ks), dof[ks], dp);
       }
       const bool need_mask = (k0 + 32 * kb + 32 > a.Nk) || (CAUSAL && (k0 + 32 * kb + 31 > q0 + off));
       const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
@@ -398,10 +450,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 dsf = acc_frag(dp, ss);
-        dq0 = mfma32(frag_tr(kl, 32 * kb + 16 * ss, 0, lane), dsf, dq0);
-        dq1 = mfma32(frag_tr(kl, 32 * kb + 16 * ss, 1, lane), dsf, dq1);
+        dq0 = mfma32(frag_tr(kl, la, 32 * kb + 16 * ss, 0), dsf, dq0);
+        dq1 = mfma32(frag_tr(kl, la, 32 * kb + 16 * ss, 1), dsf, dq1);
       }
     }
+  };
+  if (nt > 0) stage(0, 0);
+  for (int kt = 0; kt < nt; kt += 2) {
+    tile(ic<0>{}, kt);
+    if (kt + 1 < nt) tile(ic<1>{}, kt + 1);
   }
   if (qabs < a.Nq) {
     u16* dqp = a.dq + b * a.dq_bs + (int64_t)qabs * a.dq_rs + h * 64;

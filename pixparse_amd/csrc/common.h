@@ -44,12 +44,29 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
-// exact (erf) GELU and its derivative, fp32
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU and its derivative in fp32.  erf by Abramowitz-Stegun 7.1.26 (|abs error| < 1.5e-7, far below the bf16
+// rounding of the result) with hardware rcp / exp2: ~14 VALU issues per element instead of libm erff's ~40 -- the
+// GEMM epilogues run 128 of these per lane with no second workgroup on the CU to hide them behind.
+__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {  // erf(x/sqrt2), exp(-x^2/2)
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * gauss;
+  erf_v = copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e, g;
+  erf_parts(x, e, g);
+  return 0.5f * x * (1.0f + e);
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e, g;
+  erf_parts(x, e, g);
+  return __builtin_fmaf(x * 0.39894228040143268f, g, 0.5f * (1.0f + e));
 }
 
 // ---- wave64 reductions ----------------------------------------------------------------------

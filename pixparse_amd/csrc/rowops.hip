@@ -144,12 +144,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-__global__ void ln_bwd_reduce(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma,
-                              float* __restrict__ dbeta, int acc) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * D) return;
+// sum of the per-block partials: 64 columns per workgroup, 4 row groups of partial blocks, LDS combine
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int acc) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * 2 * D + idx];
+  if (idx < 2 * D)
+    for (int b = rg; b < nblk; b += 4) s += ws[(size_t)b * 2 * D + idx];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg != 0 || idx >= 2 * D) return;
+  s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
   float* base = idx < D ? dgamma : dbeta;
   if (!base) return;
   float* dst = base + (idx < D ? idx : idx - D);
@@ -367,7 +374,7 @@ extern "C" int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const
                                                              dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws);
   CRL_LAUNCH_CHECK("crl_layernorm_bwd");
   if (dgamma || dbeta) {
-    ln_bwd_reduce<<<blocks_for(2 * D, 256), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad);
+    ln_bwd_reduce<<<blocks_for(2 * D, 64), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad);
     CRL_LAUNCH_CHECK("crl_layernorm_bwd(reduce)");
   }
   return 0;
