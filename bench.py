@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps K --warmup W
 
-A "step" = one TaskCrullerPretrain.train_step(sample) on synthetic inputs already converted to
-device tensors' source (pinned host batch of B docs): H2D, forward, CE, backward (+bucketed
-all-reduce), unscale/clip/AdamW/zero_grad, LR update.  Workload at N=1 = BASELINE.json configs[2]:
+A "step" = one TaskCrullerPretrain.train_step(sample) on a synthetic batch of B docs already resident in HBM
+(--host-inputs feeds pinned host batches instead): token shift, forward, CE, backward (+bucketed all-reduce),
+unscale/clip/AdamW/zero_grad, LR update.  Workload at N=1 = BASELINE.json configs[2]:
 cruller_large (ViT-L/14 CLIP + BART-large 10L) bf16, 1280x960x3, 1024 tokens, batch 8 per GPU.
 Prints ONE JSON line (rank 0) with the driver's contract + `roofline` + `cpu_baseline`.
 """
@@ -153,6 +153,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--host-inputs', action='store_true', help='feed pinned host batches (PCIe-inclusive rate) instead of HBM-resident ones')
     args = ap.parse_args()
 
     from pixparse_amd.data import SyntheticLoaderBundle
@@ -170,7 +171,8 @@ def main():
     m = task.model
     nb = args.steps + args.warmup
     loader = SyntheticLoaderBundle(batch_size=args.batch, num_batches=nb, in_chans=m.in_chans, img_size=m.img_size,
-                                   max_length=m.max_length, vocab_size=task.vocab_size, seed=42, rank=env.global_rank)
+                                   max_length=m.max_length, vocab_size=task.vocab_size, seed=42, rank=env.global_rank,
+                                   device=None if args.host_inputs else env.device)
     task.train_setup(num_batches_per_interval=max(nb, 100))
     task.train_interval_start()
     it = iter(loader.loader)
@@ -203,7 +205,8 @@ def main():
     out = {
         'metric': METRIC, 'value': round(value, 4), 'unit': 'docs/s', 'n_gpus': env.world_size, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16', 'data': 'synthetic (N(0,1) images, uniform random full-length targets), random-init weights',
+        'dtype': 'bf16', 'data': 'synthetic (N(0,1) images, uniform random full-length targets), random-init weights, inputs ' +
+        ('in pinned host memory (H2D inside the step)' if args.host_inputs else 'resident in HBM'),
         'config': {'workload': f'{args.model}: {m.cfg.image_encoder.name} @ {m.img_size[0]}x{m.img_size[1]}x{m.in_chans} + '
                                f'{m.cfg.text_decoder.name} {m.n_layers}L, {m.max_length}-token targets, V={task.vocab_size}, '
                                f'per-GPU batch {args.batch}, AdamW + clip-norm 1.0, dropout off',

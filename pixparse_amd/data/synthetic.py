@@ -50,10 +50,13 @@ class SyntheticLoaderBundle:
     distinct: int = 2
     ragged: bool = False
     sampler: Optional[object] = None
+    device: Optional[object] = None   # put the batches in HBM up front (bench: inputs resident before the timed region)
 
     def __post_init__(self):
         self.samples = [synthetic_batch(self.batch_size, self.in_chans, self.img_size, self.max_length, self.vocab_size,
-                                        self.seed + 1000 * i, self.rank, self.ragged, pin=True) for i in range(self.distinct)]
+                                        self.seed + 1000 * i, self.rank, self.ragged, pin=self.device is None) for i in range(self.distinct)]
+        if self.device is not None:
+            self.samples = [tuple(t.to(self.device) for t in smp) for smp in self.samples]
         self.num_samples = self.num_batches * self.batch_size
         self.loader = _Iter(self)
 
