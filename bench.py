@@ -87,7 +87,7 @@ def dominant_kernel_roofline(task, B):
     q3 = qkv.view(B, N, 3 * D)
     do = torch.randn(B, N, D, device=qkv.device).to(torch.bfloat16)
     dqkv = torch.empty_like(qkv).view(B, N, 3 * D)
-    delta = torch.empty(B, H, N, device=qkv.device)
+    delta = torch.empty(2, B, H, N, device=qkv.device)
     o2 = torch.empty_like(o)
     lse2 = torch.empty_like(lse)
     h2, act, pre = T['vit.b0.ln2.y16'], torch.empty_like(T['vit.b0.act']), torch.empty_like(T['vit.b0.pre'])
@@ -95,13 +95,23 @@ def dominant_kernel_roofline(task, B):
     cand = {}
     t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False))
     cand['attn_fwd_kernel<false> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
-    t = time_kernel(lambda: ops.attn_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do, lse, delta,
-                                         dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False))
-    cand['attn_bwd (delta + dkdv + dq kernels, ViT MHSA bwd)'] = (t, 8.0 * N * N * D * B, depth)   # algorithmic bwd = 2x fwd
+    from pixparse_amd import hip
+    bwd = lambda: ops.attn_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do, lse, delta,
+                               dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False)
+    bwd()   # fills the delta / lse row constants once
+    # algorithmic backward = 4 products (dV, dP, dK, dQ = 2x forward); the dK/dV pass carries 3 of them (+ S recomputed),
+    # the dQ pass 1 (+ S, dP recomputed): executed 4 and 3 products.
+    hip.call('crl_attn_bwd_set_parts', 2)
+    t = time_kernel(bwd)
+    cand['attn_bwd_dkdv_kernel<false> (ViT MHSA bwd, dK/dV pass)'] = (t, 6.0 * N * N * D * B, depth)
+    hip.call('crl_attn_bwd_set_parts', 4)
+    t = time_kernel(bwd)
+    cand['attn_bwd_dq_kernel<false> (ViT MHSA bwd, dQ pass)'] = (t, 2.0 * N * N * D * B, depth)
+    hip.call('crl_attn_bwd_set_parts', 7)
     t = time_kernel(lambda: ops.linear_fwd(h2, w1, b1, act, ops.EPI_BF16_GELU, aux=pre))
     # per block: qkv (3D) + proj (D) + fc1 (F) + fc2 (F) columns forward, twice that again in backward
     gemm_equiv = 3.0 * (3 * D + D + 2 * F) / F
-    cand['gemm_kernel<NT,GELU,64> (fc1 49512x4096x1024)'] = (t, 2.0 * M * F * D, depth * gemm_equiv)
+    cand['gemm256_kernel<NT,GELU> (fc1 49512x4096x1024; stands for all encoder GEMM launches)'] = (t, 2.0 * M * F * D, depth * gemm_equiv)
     best = max(cand.items(), key=lambda kv: kv[1][0] * kv[1][2])
     name, (ms, flops, cnt) = best
     achieved = flops / (ms * 1e-3) / 1e12

@@ -138,7 +138,7 @@ __device__ __forceinline__ void block_to_bh_tile(int bid, int ntile, int BH, int
 template <int V> using ic = std::integral_constant<int, V>;
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,8 +165,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
   const int nt = kend > 0 ? (kend + 63) / 64 : 0;
 
-  f32x16 o0 = zero16(), o1 = zero16();
-  float m = -INFINITY, l = 0.f;
+  // o2 is a third dv block whose V^T operand is the constant [1,0,...,0]^T: row 0 of O2^T accumulates the row sums
+  // l = sum_k bf16(p) on the MFMA pipe (which has slack at head_dim 64) instead of 32 VALU adds per tile
+  f32x16 o0 = zero16(), o1 = zero16(), o2 = zero16();
+  float m = -INFINITY;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)((lane & 31) == 0 ? 1.0f : 0.0f);
   const float c = a.scale * LOG2E;
   const int qabs = q0 + qi;
 
@@ -209,19 +214,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     if (__any(m_new != m)) {                       // wave-uniform: most tiles leave every running max untouched
       const float alpha = __builtin_amdgcn_exp2f(m - m_use);
-      l *= alpha;
+      o2[0] *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
       m = m_new;
     }
-    float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -m_use));
       s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -m_use));
-      ps += s0[r] + s1[r];
     }
-    l += ps;
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
       o1 = mfma32(frag_tr(vl, la, 16 * s, 1), p0, o1);
       o0 = mfma32(frag_tr(vl, la, 32 + 16 * s, 0), p1, o0);
       o1 = mfma32(frag_tr(vl, la, 32 + 16 * s, 1), p1, o1);
+      o2 = mfma32(ones, p0, o2);
+      o2 = mfma32(ones, p1, o2);
     }
   };
   if (nt > 0) stage(0, 0);
@@ -237,6 +241,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     tile(ic<0>{}, kt);
     if (kt + 1 < nt) tile(ic<1>{}, kt + 1);
   }
+  float l = o2[0];            // row 0 of O2^T lives in register 0 of the hh == 0 lanes
+  if (hh) l = 0.f;
   l += swap32(l);
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (qabs < a.Nq) {
@@ -269,7 +275,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
     for (int j = 0; j < 4; ++j) s += bf2f(xw[j] & 0xffff) * bf2f(yw[j] & 0xffff) + bf2f(xw[j] >> 16) * bf2f(yw[j] >> 16);
   }
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (r < total && sub == 0) a.delta[r] = s;
+  if (r < total && sub == 0) {
+    a.delta[r] = -s;                              // accumulator init of dP:  dP - delta
+    a.delta[total + r] = -a.lse[r] / a.scale;     // accumulator init of S:   (S - lse/scale) * scale*log2e = log2 P
+  }
 }
 
 // ======================================================================================= dK, dV
@@ -288,8 +297,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
 
   const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
   const u32x4 rdo = make_srd(a.d_o + b * a.do_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
-  const u32x4 rl = make_srd(a.lse + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);
-  const u32x4 rd = make_srd(a.delta + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);
+  const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
+  const u32x4 rl = make_srd(a.delta + nrows + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);   // -lse/scale
+  const u32x4 rd = make_srd(a.delta + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);          // -delta
   const uint32_t sbase = lds_addr_of(smem);
   const LaneAddr la = make_lane_addr(lane);
   const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs);
@@ -330,7 +340,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
     const float* del_s = lse_s + 64;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s = zero16(), dp = zero16();
+      // accumulators start from the per-query row constants (-lse/scale, -delta) read straight from LDS, so the
+      // MFMA chains leave S - lse/scale and dP - delta: no subtract / rescale VALU work per element
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+        const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
+        s[4 * g4] = L.x; s[4 * g4 + 1] = L.y; s[4 * g4 + 2] = L.z; s[4 * g4 + 3] = L.w;
+        dp[4 * g4] = Dl.x; dp[4 * g4 + 1] = Dl.y; dp[4 * g4 + 2] = Dl.z; dp[4 * g4 + 3] = Dl.w;
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(frag_row(ql, la, 32 * qb, ks), kf[ks], s);
@@ -339,18 +358,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
       const int qbase = t * 64 + 32 * qb;
       const bool need_mask = CAUSAL && (key0 + 31 > qbase + off);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
-        const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
-        const float Lv[4] = {L.x * LOG2E, L.y * LOG2E, L.z * LOG2E, L.w * LOG2E}, Dv[4] = {Dl.x, Dl.y, Dl.z, Dl.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * g4 + i;
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lv[i]));
-          if (need_mask && (kabs > qbase + 8 * g4 + 4 * hh + i + off)) p = 0.f;
-          s[r] = p;
-          dp[r] = p * (dp[r] - Dv[i]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[r] * c);
+        if (need_mask && (kabs > qbase + acc_row(r, hh) + off)) p = 0.f;
+        s[r] = p;
+        dp[r] = p * dp[r];
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -410,8 +422,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     qf[ks] = *reinterpret_cast<const bf16x8*>(a.q + b * a.q_bs + (int64_t)qrow * a.q_rs + h * 64 + 16 * ks + 8 * hh);
     dof[ks] = *reinterpret_cast<const bf16x8*>(a.d_o + b * a.do_bs + (int64_t)qrow * a.do_rs + h * 64 + 16 * ks + 8 * hh);
   }
-  const float L = a.lse[((int64_t)b * a.H + h) * a.Nq + qrow] * LOG2E;
-  const float Dl = a.delta[((int64_t)b * a.H + h) * a.Nq + qrow];
+  // per-lane row constants as persistent accumulator seeds (query on the lane)
+  const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
+  const float nL = a.delta[nrows + ((int64_t)b * a.H + h) * a.Nq + qrow];   // -lse/scale
+  const float nD = a.delta[((int64_t)b * a.H + h) * a.Nq + qrow];           // -delta
+  f32x16 seedS, seedD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { seedS[r] = nL; seedD[r] = nD; }
 
   int kend = a.Nk;
   if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int k0 = kt * 64;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16(), dp = zero16();
+      f32x16 s = seedS, dp = seedD;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(frag_row(kl, la, 32 * kb, ks), qf[ks], s);
@@ -443,9 +460,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L));
+        float p = __builtin_amdgcn_exp2f(s[r] * c);
         if (need_mask && (k0 + 32 * kb + acc_row(r, hh) > lim)) p = 0.f;  // also keeps exp(-lse) of zero-filled keys out
-        dp[r] = p * (dp[r] - Dl);
+        dp[r] = p * dp[r];
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -503,6 +520,14 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   return 0;
 }
 
+static int g_bwd_parts = 7;
+// measurement hook: which of the three backward launches crl_attn_bwd issues (bit0 delta, bit1 dK/dV, bit2 dQ); default all
+extern "C" int crl_attn_bwd_set_parts(int parts) {
+  if (parts < 1 || parts > 7) { crl_set_error("crl_attn_bwd_set_parts: bad mask %d", parts); return -1; }
+  g_bwd_parts = parts;
+  return 0;
+}
+
 extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                             const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                             const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
@@ -524,12 +549,14 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   a.nqt = (Nq + 127) / 128; a.nkt = (Nk + 127) / 128;
   hipStream_t s = as_stream(stream);
   const int64_t rows = (int64_t)B * H * Nq;
-  attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
-  CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
+  if (g_bwd_parts & 1) {
+    attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
+    CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
+  }
   const unsigned gk = (unsigned)a.nkt * B * H, gq = (unsigned)a.nqt * B * H;
-  if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
+  if (g_bwd_parts & 2) { if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a); }
   CRL_LAUNCH_CHECK("crl_attn_bwd(dkdv)");
-  if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
+  if (g_bwd_parts & 4) { if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a); }
   CRL_LAUNCH_CHECK("crl_attn_bwd(dq)");
   return 0;
 }

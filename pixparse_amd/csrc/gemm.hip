@@ -271,7 +271,42 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk reduce)");
     return 0;
   }
-  if (p.big) return crl_gemm256_launch(layout, epilogue, a, 1, s);
+  if (p.big) {
+    // Wave quantisation: the 256x256 kernel runs one workgroup per CU, so R*ntn tiles cost ceil(R*ntn/256) full tile
+    // times.  When trimming a few row tiles lands on a whole number of waves, the big kernel takes the first 256*R rows
+    // and the remaining rows (< 9 row tiles) go to the 128x128 kernel, whose small tiles pack 2 per CU.
+    const int64_t ntn = a.ntn, rmax = M / 256;
+    int64_t best_r = -1;
+    double best_cost = (double)((((M + 255) / 256) * ntn + 255) / 256);   // in units of one 256-tile time
+    if (layout != CRL_TN) {
+      for (int64_t r = rmax; r >= 1 && r >= rmax - 8; --r) {
+        const int64_t rem = M - 256 * r;
+        if (rem <= 0) continue;
+        const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 511) / 512);
+        const double cost = (double)((r * ntn + 255) / 256) + small;
+        if (cost < best_cost - 0.2) { best_cost = cost; best_r = r; }
+      }
+    }
+    if (best_r < 0) return crl_gemm256_launch(layout, epilogue, a, 1, s);
+    const int64_t m1 = 256 * best_r;
+    GemmArgs big = a;
+    big.M = (int)m1; big.ntm = (int)best_r;
+    if (int rc = crl_gemm256_launch(layout, epilogue, big, 1, s)) return rc;
+    GemmArgs rest = a;
+    const bool c32 = epilogue >= CRL_EPI_F32_RESID;
+    rest.A = a.A + m1 * lda;
+    rest.C = (char*)a.C + m1 * ldc * (c32 ? 4 : 2);
+    if (a.aux) rest.aux = (char*)a.aux + m1 * ldaux * 2;
+    if (a.resid) rest.resid = a.resid + m1 * ldr;
+    rest.M = (int)(M - m1);
+    rest.a_bytes = (uint32_t)(((M - m1 - 1) * lda + K) * 2);
+    rest.ntm = (int)((M - m1 + BM - 1) / BM); rest.ntn = (int)((N + BN - 1) / BN);
+    rest.kchunk = (int)((K + 63) / 64);
+    switch (layout) {
+      case CRL_NT: return launch_epi<CRL_NT>(rest, epilogue, 64, 1, s);
+      default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, s);
+    }
+  }
   switch (layout) {
     case CRL_NT: return launch_epi<CRL_NT>(a, epilogue, bk, 1, s);
     case CRL_NN: return launch_epi<CRL_NN>(a, epilogue, bk, 1, s);

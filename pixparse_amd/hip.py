@@ -27,6 +27,7 @@ SIGNATURES = {
     'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, P]),
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
                          I, I, I, I, F, I, P]),
+    'crl_attn_bwd_set_parts': (I, [I]),
     'crl_swin_attn_fwd': (I, [P, P, P, I, I, I, I, I, I, F, P]),
     'crl_swin_attn_bwd': (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     'crl_patch_merge_fwd': (I, [P, P, I, I, I, I, P]),

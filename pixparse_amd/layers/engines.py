@@ -190,7 +190,7 @@ class ViTEngine(_Base):
         dh = self.buf('dh', (M, D), BF16)
         do = self.buf('do', (M, D), BF16)
         dqkv = self.buf('dqkv', (M, 3 * D), BF16)
-        delta = self.buf('delta', (B, self.heads, N), F32)
+        delta = self.buf('delta', (2, B, self.heads, N), F32)
         for i in reversed(range(a['depth'])):
             bp, k = f'blocks.{i}.', f'b{i}'
             xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
@@ -504,7 +504,7 @@ class BartEngine(_Base):
         dq2 = self.buf('dq2', (M, D), BF16)
         dkv2 = self.buf('dkv2', (Me, 2 * D), BF16)
         dqkv = self.buf('dqkv', (M, 3 * D), BF16)
-        delta = self.buf('delta', (B, H, T), F32)
+        delta = self.buf('delta', (2, B, H, T), F32)
         for i in reversed(range(self.L)):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             g = lambda n: Tb[tg + k + n]

@@ -1,6 +1,6 @@
 """micro-benchmarks of the hot kernels on random data (HIP events); run on the GPU box"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pixparse_amd import hip, ops
 dev = torch.device('cuda:0')
 BF16 = torch.bfloat16
@@ -42,6 +42,16 @@ if __name__ == '__main__':
             gemm_case('square 8192', 'NT', 8192, 8192, 8192, policy=pol)
             gemm_case('square 4096', 'NT', 4096, 4096, 4096, policy=pol)
         M = 49512
+        for pol in (1, 2):
+            gemm_case('proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, policy=pol)
+            gemm_case('qkv', 'NT', M, 3072, 1024, policy=pol)
+            gemm_case('fc2 resid', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, policy=pol)
+            gemm_case('dgrad proj', 'NN', M, 1024, 1024, policy=pol)
+            gemm_case('wgrad proj', 'TN', M, 1024, 1024, policy=pol)
+            gemm_case('wgrad fc1', 'TN', M, 4096, 1024, policy=pol)
+            gemm_case('dec qkv', 'NT', 8184, 3072, 1024, policy=pol)
+            gemm_case('dec fc1', 'NT', 8184, 4096, 1024, ops.EPI_BF16_GELU, policy=pol)
+            gemm_case('dec out resid', 'NT', 8184, 1024, 1024, ops.EPI_F32_RESID, policy=pol)
         gemm_case('qkv', 'NT', M, 3072, 1024)
         gemm_case('proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID)
         gemm_case('fc1 gelu', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU)
@@ -58,7 +68,7 @@ if __name__ == '__main__':
         D = H * 64
         qkv = torch.randn(B, N, 3 * D, device=dev).to(BF16)
         o = torch.empty(B, N, D, dtype=BF16, device=dev); lse = torch.empty(B, H, N, device=dev)
-        do = torch.randn(B, N, D, device=dev).to(BF16); dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device=dev)
+        do = torch.randn(B, N, D, device=dev).to(BF16); dqkv = torch.empty_like(qkv); delta = torch.empty(2, B, H, N, device=dev)
         q, k, v = qkv[:, :, :D], qkv[:, :, D:2*D], qkv[:, :, 2*D:]
         ms = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, H, 0.125, False))
         fl = 4.0 * N * N * D * B

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pixparse_amd import hip, ops
 dev = torch.device('cuda:0')
 BF16 = torch.bfloat16

@@ -146,6 +146,30 @@ def test_gemm_256_kernel_all_layouts(dev, K):
         hip.call('crl_gemm_set_policy', 0)
 
 
+def test_gemm_wave_quantisation_split(dev):
+    """auto policy, 17 x 16 tiles of 256: the big kernel takes 16 row tiles (one full wave), the 128 kernel the last 104 rows"""
+    from pixparse_amd import ops
+    M, N, K = 256 * 16 + 104, 4096, 128
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    ref = x.float() @ w.float().t() + bias.to(BF16).float()
+    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    act = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=pre)
+    close(pre, ref, 1e-2, 1e-2, 'split aux')
+    close(act, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, 'split gelu')
+    y = rnd((M, N), dev, 1.0, 4)
+    want = y + ref.to(BF16).float()
+    ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+    close(y, want, 1e-2, 2e-2, 'split resid')
+    dy = rnd((M, K), dev, 1.0, 5, BF16)          # NN: out[M, N] = dy[M, K] @ w2[K, N]
+    w2 = rnd((K, N), dev, 0.1, 6, BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_dgrad(dy, w2, out)
+    close(out, dy.float() @ w2.float(), 1e-2, 1e-2, 'split NN')
+
+
 def test_gemm_256_splitk_wgrad(dev):
     from pixparse_amd import hip, ops
     Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
@@ -306,7 +330,7 @@ def test_attention_fwd_bwd(dev, B, H, Nq, Nk, causal):
     close(lse, lref, 1e-3, 2e-3, 'attn lse')
     d_o = rnd((B, Nq, D), dev, 1.0, 5, BF16)
     oref.backward(hd(d_o, Nq))
-    delta = torch.empty(B, H, Nq, device=dev)
+    delta = torch.empty(2, B, H, Nq, device=dev)
     if Nq == Nk:
         dqkv = torch.zeros(B, Nq, 3 * D, dtype=BF16, device=dev)
         dq, dk, dv = dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:]
