@@ -13,6 +13,10 @@ LIB = os.path.join(CSRC, 'libcruller_hip.so')
 SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'capi.cpp']
 HEADERS = ['common.h', 'gemm_common.h', os.path.join('..', '..', 'include', 'crl.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+# per-file extras: hipcc's SLP vectoriser packs the softmax / dS multiplies of the attention kernels into v_pk_mul_f32 on
+# misaligned register pairs and then spends ~25 v_mov / v_perm / v_alignbit per 32x32 block re-assembling the bf16 MFMA
+# operand; these kernels are VALU-issue bound, so it is switched off for them.
+EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -38,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
             jobs.append(cmd)
 
     def run(cmd):

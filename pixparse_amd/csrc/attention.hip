@@ -357,10 +357,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
       }
       const int qbase = t * 64 + 32 * qb;
       const bool need_mask = CAUSAL && (key0 + 31 > qbase + off);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kabs > qbase + acc_row(r, hh) + off) s[r] = -INFINITY;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[r] * c);
-        if (need_mask && (kabs > qbase + acc_row(r, hh) + off)) p = 0.f;
+        const float p = __builtin_amdgcn_exp2f(s[r] * c);
         s[r] = p;
         dp[r] = p * dp[r];
       }
@@ -458,12 +462,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       }
       const bool need_mask = (k0 + 32 * kb + 32 > a.Nk) || (CAUSAL && (k0 + 32 * kb + 31 > q0 + off));
       const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
+      if (need_mask) {   // wave-uniform branch: only ragged / diagonal tiles pay for the compares
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[r] * c);
-        if (need_mask && (k0 + 32 * kb + acc_row(r, hh) > lim)) p = 0.f;  // also keeps exp(-lse) of zero-filled keys out
-        dp[r] = p * dp[r];
+        for (int r = 0; r < 16; ++r)
+          if (k0 + 32 * kb + acc_row(r, hh) > lim) s[r] = -INFINITY;   // also keeps exp(-lse) of zero-filled keys out
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 dsf = acc_frag(dp, ss);
