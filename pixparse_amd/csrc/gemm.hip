@@ -202,7 +202,7 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
     return ns < 1 ? 1 : ns;
   };
   if (k64 && g_policy != 1 && ((M >= 256 && N >= 256) || g_policy == 2)) {
-    const int ns = split_for(t256, 512);
+    const int ns = split_for(t256, 256);   // one workgroup per CU: aim at one full wave of split tiles
     if (t256 * ns >= 192 || g_policy == 2) { p.big = true; p.nsplit = ns; }
   }
   if (!p.big) p.nsplit = k64 ? split_for(t128, 768) : 1;

@@ -317,3 +317,15 @@ def test_bucketed_reducer_two_gloo_ranks():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_app_flag_surface():
+    """reference flag spelling (README.md:19-40): nested dataclass flags with dash or underscore variants"""
+    from pixparse_amd.app.train import parse_args
+    t, k, d = parse_args(['--task.model-name', 'cruller_small', '--task.dtype', 'bfloat16', '--task.opt.learning-rate', '3e-4',
+                          '--task.opt.betas', '0.9 0.98', '--task.opt.clip_grad_value', '1.0', '--task.opt.clip-grad-mode', 'norm',
+                          '--task.opt.grad-accum-steps', '4', '--data.train.batch-size', '2', '--train.num-intervals', '3',
+                          '--train.output-dir', '/tmp/x'])
+    assert k.model_name == 'cruller_small' and k.model.image_encoder.name == 'swin_tiny_patch4_window7_224'
+    assert k.opt.learning_rate == 3e-4 and k.opt.betas == (0.9, 0.98) and k.opt.clip_grad_value == 1.0 and k.opt.grad_accum_steps == 4
+    assert t.num_intervals == 3 and t.output_dir == '/tmp/x' and d.batch_size == 2 and k.dtype == 'bfloat16'

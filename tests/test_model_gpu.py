@@ -169,3 +169,25 @@ def test_task_train_steps_vs_oracle_trainer(dev):
     assert rel(task.model.state_dict()[k], tr.params[k].detach()) < 1e-3
     sd = task.state_dict()
     assert set(sd) == {'model', 'optimizer', 'scheduler', 'scaler'}
+
+
+def test_app_train_checkpoint_roundtrip(dev, tmp_path):
+    """python -m pixparse_amd.app.train on cfg-1 (cruller_small: swin_tiny + BART-base 2L, 224x224, 128 tokens, batch 2):
+    two intervals, checkpoint-{i}.pt = model.state_dict() with reference key names, reload (with a DDP 'module.' prefix)"""
+    from pixparse_amd.app.train import main
+    from pixparse_amd.models import Cruller, get_model_config
+    out = str(tmp_path)
+    main(['--task.model-name', 'cruller_small', '--task.dtype', 'bfloat16', '--task.opt.learning-rate', '1e-3', '--task.opt.betas', '0.9 0.98',
+          '--task.opt.clip-grad-value', '1.0', '--task.opt.clip-grad-mode', 'norm', '--task.num-warmup-intervals', '1',
+          '--data.train.batch-size', '2', '--data.train.num-batches', '3', '--train.num-intervals', '2', '--train.output-dir', out,
+          '--train.experiment', 'exp'])
+    ck = os.path.join(out, 'exp', 'checkpoints')
+    assert sorted(os.listdir(ck)) == ['checkpoint-0.pt', 'checkpoint-1.pt']
+    sd0 = torch.load(os.path.join(ck, 'checkpoint-0.pt'), map_location='cpu')
+    sd1 = torch.load(os.path.join(ck, 'checkpoint-1.pt'), map_location='cpu')
+    k = 'image_encoder.trunk.layers.2.blocks.3.mlp.fc1.weight'
+    assert k in sd1 and 'text_decoder.trunk.lm_head.weight' in sd1 and sd1[k].shape == (1536, 384)
+    assert not torch.equal(sd0[k], sd1[k]) and torch.isfinite(sd1[k]).all()
+    model = Cruller(get_model_config('cruller_small'), vocab_size=50267)
+    model.load_state_dict({'module.' + n: v for n, v in sd1.items()} and sd1)
+    assert torch.equal(model.state_dict()[k], sd1[k])
