@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef PRIO_MFMA
+#define PRIO_MFMA 1
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -137,8 +140,11 @@ __device__ __forceinline__ void block_to_bh_tile(int bid, int ntile, int BH, int
 // ======================================================================================= forward
 template <int V> using ic = std::integral_constant<int, V>;
 
+#ifndef FWD_OCC
+#define FWD_OCC 4
+#endif
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,11 +194,13 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
     const char* vl = kl + 8192;
     const int k0 = kt * 64;
     f32x16 s0 = zero16(), s1 = zero16();
+    __builtin_amdgcn_s_setprio(PRIO_MFMA);     // waves with matrix work ready win the issue slot over waves in their softmax
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s0 = mfma32(frag_row(kl, la, 0, ks), qf[ks], s0);
       s1 = mfma32(frag_row(kl, la, 32, ks), qf[ks], s1);
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- online softmax, query on the lane, this lane holds 2 x 16 of the tile's 64 keys
     const bool need_mask = (k0 + 64 > a.Nk) || (CAUSAL && (k0 + 63 > q0 + off));
     if (need_mask) {
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
       s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -m_use));
     }
     // ---- O^T += V^T . P^T
+    __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8 p0 = acc_frag(s0, s), p1 = acc_frag(s1, s);
@@ -235,6 +244,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
       o2 = mfma32(ones, p0, o2);
       o2 = mfma32(ones, p1, o2);
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   if (nt > 0) stage(0, 0);
   for (int kt = 0; kt < nt; kt += 2) {
@@ -350,11 +360,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
         s[4 * g4] = L.x; s[4 * g4 + 1] = L.y; s[4 * g4 + 2] = L.z; s[4 * g4 + 3] = L.w;
         dp[4 * g4] = Dl.x; dp[4 * g4 + 1] = Dl.y; dp[4 * g4 + 2] = Dl.z; dp[4 * g4 + 3] = Dl.w;
       }
+      __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(frag_row(ql, la, 32 * qb, ks), kf[ks], s);
         dp = mfma32(frag_row(dol, la, 32 * qb, ks), vf[ks], dp);
       }
+      __builtin_amdgcn_s_setprio(0);
       const int qbase = t * 64 + 32 * qb;
       const bool need_mask = CAUSAL && (key0 + 31 > qbase + off);
       if (need_mask) {
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
         s[r] = p;
         dp[r] = p * dp[r];
       }
+      __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 pf = acc_frag(s, ss), dsf = acc_frag(dp, ss);
@@ -376,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
         dk0 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 0), dsf, dk0);
         dk1 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 1), dsf, dk1);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   };
   if (qstart_tile < nqt64) stage(0, qstart_tile);
@@ -455,11 +469,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s = seedS, dp = seedD;
+      __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(frag_row(kl, la, 32 * kb, ks), qf[ks], s);
         dp = mfma32(frag_row(vl, la, 32 * kb, ks), dof[ks], dp);
       }
+      __builtin_amdgcn_s_setprio(0);
       const bool need_mask = (k0 + 32 * kb + 32 > a.Nk) || (CAUSAL && (k0 + 32 * kb + 31 > q0 + off));
       const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
       if (need_mask) {   // wave-uniform branch: only ragged / diagonal tiles pay for the compares
@@ -469,12 +485,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
+      __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 dsf = acc_frag(dp, ss);
         dq0 = mfma32(frag_tr(kl, la, 32 * kb + 16 * ss, 0), dsf, dq0);
         dq1 = mfma32(frag_tr(kl, la, 32 * kb + 16 * ss, 1), dsf, dq1);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   };
   if (nt > 0) stage(0, 0);
