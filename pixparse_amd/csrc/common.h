@@ -101,7 +101,10 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 }
 // 16 B per lane: LDS[lds_base + 16*lane] <- buffer[voff + soff]   (zeros when out of range)
 __device__ __forceinline__ void dma16(u32x4 srd, uint32_t lds_base, uint32_t voff, uint32_t soff) {
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+#ifndef DMA_NOP
+#define DMA_NOP "s_nop 4\n\t"
+#endif
+  asm volatile(DMA_NOP "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 

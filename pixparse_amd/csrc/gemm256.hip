@@ -112,13 +112,28 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
       }
   };
   auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&b)[2][2]) {
-    __builtin_amdgcn_s_setprio(1);
+#ifndef G_PRIO
+#define G_PRIO 1
+#endif
+#ifndef G_ORDER
+#define G_ORDER 0
+#endif
+    __builtin_amdgcn_s_setprio(G_PRIO);
+#if G_ORDER == 0
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[i][j]) : "v"(b[j][ks]), "v"(fa[i][ks]));
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[i][j]) : "v"(b[j][ks]), "v"(fa[i][ks]));
+#endif
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -129,7 +144,10 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   BAR();
   // stagger (guide §5 template): the wr==1 waves run one barrier behind, so on every SIMD one wave is in its
   // MFMA cluster while its partner (the wave 4 slots away shares the SIMD) issues LDS reads and DMA.
-  if (wr == 1) BAR();
+#ifndef G_STAGGER
+#define G_STAGGER 1
+#endif
+  if (G_STAGGER && wr == 1) BAR();
 
   // four phases of the K tile in LDS buffer BUFI.  Half-tile sequence h = 4*tile + j (j: A0,B0,B1,A1); the phase
   // p of tile t issues h = 4t + 5 + p, i.e. (t+1,B1) (t+1,A1) (t+2,A0) (t+2,B0): every slot is re-staged >= 2 phases
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     tile_phases(std::integral_constant<int, 0>{}, te + 1, te + 2);
     tile_phases(std::integral_constant<int, 1>{}, te + 2, te + 3);
   }
-  if (wr == 0) BAR();
+  if (G_STAGGER && wr == 0) BAR();
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
 
   // ---------------- epilogue: lane (li, lq) holds C[m = .. + li][n = .. + 4 lq + 0..3]
