@@ -175,6 +175,14 @@ int crl_cast_pad_bf16(const float* src, void* dst, int64_t R, int64_t C, int64_t
 /* y_f32 (+)= float(x_bf16), elementwise (gradient joins). */
 int crl_add_bf16_to_f32(const void* x_bf16, float* y, int64_t n, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------- image preprocessing
+ * ref: task/task_cruller_pretrain.py:132-143  ToTensor -> Resize(image_size, BICUBIC, antialias=True) -> Normalize.
+ * img: uint8 [H, W, C] (decoded page); out: fp32 [C, Ho, Wo]; tmp: fp32 scratch [C, H, Wo].
+ * (xmin, xsize, xw[Wo][xk]) / (ymin, ysize, yw[Ho][yk]): aten upsample_bicubic2d_aa filter tables for W->Wo / H->Ho. */
+int crl_image_preprocess_u8(const void* img_hwc_u8, int H, int W, int C, const int32_t* xmin, const int32_t* xsize,
+                            const float* xw, int xk, const int32_t* ymin, const int32_t* ysize, const float* yw, int yk,
+                            const float* mean, const float* stdv, float* tmp, float* out_chw, int Ho, int Wo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

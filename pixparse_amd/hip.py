@@ -44,6 +44,7 @@ SIGNATURES = {
     'crl_cast_bf16': (I, [P, P, L, P]),
     'crl_cast_pad_bf16': (I, [P, P, L, L, L, P]),
     'crl_add_bf16_to_f32': (I, [P, P, L, I, P]),
+    'crl_image_preprocess_u8': (I, [P, I, I, I, P, P, P, I, P, P, P, I, P, P, P, P, I, I, P]),
 }
 
 NT, NN, TN = 0, 1, 2

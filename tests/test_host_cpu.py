@@ -329,3 +329,16 @@ def test_app_flag_surface():
     assert k.model_name == 'cruller_small' and k.model.image_encoder.name == 'swin_tiny_patch4_window7_224'
     assert k.opt.learning_rate == 3e-4 and k.opt.betas == (0.9, 0.98) and k.opt.clip_grad_value == 1.0 and k.opt.grad_accum_steps == 4
     assert t.num_intervals == 3 and t.output_dir == '/tmp/x' and d.batch_size == 2 and k.dtype == 'bfloat16'
+
+
+@pytest.mark.parametrize('i,o', [(1754, 1280), (1240, 960), (100, 37), (50, 64), (224, 224)])
+def test_aa_bicubic_tables_match_torch(i, o):
+    """filter tables of the GPU preprocess kernel == aten upsample_bicubic2d_aa (what torchvision Resize(BICUBIC, antialias) runs)"""
+    import torch.nn.functional as F
+    from pixparse_amd.data.gpu_preprocess import aa_bicubic_tables
+    xmin, xsize, w = aa_bicubic_tables(i, o)
+    x = torch.rand(1, 1, 1, i, generator=torch.Generator().manual_seed(0))
+    ref = F.interpolate(x, size=(1, o), mode='bicubic', antialias=True, align_corners=False)[0, 0, 0]
+    got = torch.stack([(w[k, :xsize[k]] * x[0, 0, 0, xmin[k]:xmin[k] + xsize[k]]).sum() for k in range(o)])
+    assert float((got - ref).abs().max()) < 2e-6
+    assert int((xmin + xsize).max()) <= i and float((w.sum(1) - 1).abs().max()) < 1e-5

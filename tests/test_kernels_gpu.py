@@ -454,3 +454,20 @@ def test_grad_norm_adamw(dev, golden_dir):
     ops.grad_norm(g, 1.0, 1.0, state)
     ops.adamw(p, g, m, v, pb, 1e-3, 0.9, 0.98, 1e-6, 0.0, 4, state, False)
     assert float(state[2]) == 1.0 and torch.equal(p, before)
+
+
+@pytest.mark.parametrize('H,W,C,Ho,Wo', [(877, 620, 3, 1280, 960), (1754, 1240, 1, 960, 640), (300, 200, 3, 224, 224)])
+def test_gpu_image_preprocess(dev, H, W, C, Ho, Wo):
+    """uint8 page -> ToTensor -> bicubic antialias Resize -> Normalize on the GPU vs the same ops in torch (CPU)"""
+    import torch.nn.functional as F
+    from pixparse_amd.data.gpu_preprocess import GpuImagePreprocess
+    g = torch.Generator().manual_seed(1)
+    img = torch.randint(0, 256, (H, W, C), generator=g, dtype=torch.uint8)
+    mean, std = [0.48, 0.45, 0.40][:C], [0.27, 0.26, 0.28][:C]
+    pre = GpuImagePreprocess((Ho, Wo), mean, std, C, dev)
+    out = pre(img)
+    x = img.permute(2, 0, 1).float() / 255.0
+    ref = F.interpolate(x[None], size=(Ho, Wo), mode='bicubic', antialias=True, align_corners=False)[0]
+    ref = (ref - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)
+    assert out.shape == (C, Ho, Wo)
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
