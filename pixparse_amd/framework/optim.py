@@ -41,7 +41,7 @@ class ArenaAdamW:
 
     def state_dict(self):
         return dict(step=self.step_count, param_groups=[dict(g) for g in self.param_groups],
-                    exp_avg=self.arena.m, exp_avg_sq=self.arena.v)
+                    exp_avg=self.arena.m.clone(), exp_avg_sq=self.arena.v.clone())
 
     def load_state_dict(self, sd):
         self.step_count = sd['step']

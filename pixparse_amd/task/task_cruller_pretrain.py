@@ -204,5 +204,25 @@ class TaskCrullerPretrain(TaskTrain):
     def load_state_dict(self, state_dict):
         pass  # like the reference (:382-383)
 
+    # ---- full resume (the reference saves model weights only and cannot resume pretraining, Q5)
+    def training_state(self):
+        """state_dict() + the counters needed to continue the run exactly"""
+        sd = self.state_dict()
+        sd['counters'] = dict(step=self.step, batch_idx=self.batch_idx, interval_idx=self.interval_idx,
+                              interval_batch_idx=self.interval_batch_idx)
+        return sd
+
+    def load_training_state(self, sd):
+        """call after train_setup(); accepts DDP-style 'module.' prefixed model keys (ref app/eval.py:135)"""
+        model_sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd['model'].items()}
+        self.model.load_state_dict(model_sd)
+        self.model.refresh_shadows(full=True)
+        self.optimizer.load_state_dict(sd['optimizer'])
+        if 'scaler' in sd and self.scaler is not None:
+            self.scaler.load_state_dict(sd['scaler'])
+        for k, v in sd.get('counters', {}).items():
+            setattr(self, k, v)
+        self.scheduler.step_update(self.step)
+
     def __repr__(self):
         return '\n'.join([f'model: {self.model.cfg}', f'opt: {repr(self.optimizer)}', f'sched: {repr(self.scheduler)}'])

@@ -191,3 +191,42 @@ def test_app_train_checkpoint_roundtrip(dev, tmp_path):
     model = Cruller(get_model_config('cruller_small'), vocab_size=50267)
     model.load_state_dict({'module.' + n: v for n, v in sd1.items()} and sd1)
     assert torch.equal(model.state_dict()[k], sd1[k])
+
+
+def test_resume_continues_identically(dev):
+    """f-2: training_state() / load_training_state(): an interrupted run continues on the same loss trajectory"""
+    from oracle import ref_cpu as R
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    _register_test_archs()
+    L, layers, img = 24, 2, (37, 50)
+
+    def make():
+        cfg = TaskCrullerPretrainCfg(num_intervals=4, num_warmup_intervals=1, eval_frequency=1000, dtype='bfloat16',
+                                     opt=OptimizationCfg(learning_rate=1e-3, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm'),
+                                     model=_cfg('vit_test', img, 'RGB', layers, L))
+        torch.manual_seed(5)
+        t = TaskCrullerPretrain(cfg, DeviceEnv())
+        t.train_setup(num_batches_per_interval=2)
+        t.train_interval_start()
+        return t
+    spec = R.ModelSpec('vit_test', 'bart_test', layers, L, img, 3, vocab=50267)
+    samples = [R.synthetic_sample(spec, 2, seed=30 + i, ragged=True) for i in range(4)]
+    a = make()
+    for s in samples[:2]:
+        a.train_step(s)
+    snap = {k: (v if not isinstance(v, dict) else {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()})
+            for k, v in a.training_state().items()}
+    snap['model'] = {'module.' + k: v.clone() for k, v in snap['model'].items()}     # as a DDP checkpoint would name them
+    la = []
+    for s in samples[2:]:
+        a.train_step(s)
+        la.append(float(a.last_loss))
+    b = make()
+    b.load_training_state(snap)
+    assert b.step == 2 and abs(b.get_current_lr() - R.cosine_lr(2, 1e-3, 2, 8)) < 1e-12
+    lb = []
+    for s in samples[2:]:
+        b.train_step(s)
+        lb.append(float(b.last_loss))
+    assert all(abs(x - y) < 1e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
