@@ -75,3 +75,10 @@ if __name__ == '__main__':
         print(f'attn fwd  {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s (algorithmic)')
         ms = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2*D], dqkv[:, :, 2*D:], H, 0.125, False))
         print(f'attn bwd  {ms:7.3f} ms {2*fl/ms/1e9:7.1f} TF/s (algorithmic 2x fwd; executed 3.5x)')
+        bwd = lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2*D], dqkv[:, :, 2*D:], H, 0.125, False)
+        for rep in range(2):   # the two backward passes separately (crl_attn_bwd_set_parts)
+            for name, mask in (('dkdv', 2), ('dq', 4)):
+                hip.call('crl_attn_bwd_set_parts', mask)
+                ms = timeit(bwd, 10)
+                print(f'attn bwd part {name:12s} {ms:7.3f} ms')
+        hip.call('crl_attn_bwd_set_parts', 7)

@@ -307,7 +307,9 @@ def attn_ref(q, k, v, scale, causal):
 
 
 @pytest.mark.parametrize('B,H,Nq,Nk,causal', [(2, 2, 200, 200, False), (1, 3, 127, 333, False), (2, 2, 255, 255, True),
-                                               (1, 8, 64, 64, False), (1, 1, 1, 70, False), (1, 2, 300, 300, True)])
+                                               (1, 8, 64, 64, False), (1, 1, 1, 70, False), (1, 2, 300, 300, True),
+                                               (1, 2, 700, 700, False), (1, 1, 530, 530, True), (1, 2, 300, 900, False),
+                                               (1, 1, 257, 449, True)])
 def test_attention_fwd_bwd(dev, B, H, Nq, Nk, causal):
     from pixparse_amd import ops
     d, D = 64, H * 64
