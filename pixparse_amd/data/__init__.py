@@ -1,2 +1,3 @@
 from .preprocess import preprocess_ocr_anno, preprocess_text_anno, mask_targets
 from .synthetic import SyntheticLoaderBundle, synthetic_batch
+from .gpu_preprocess import GpuImagePreprocess, aa_bicubic_tables

@@ -79,8 +79,14 @@ class DeviceEnv:
             assert init_device_index is None
             self.local_rank = int(init_local_rank)
             backend = init_dist_backend if use_cuda else 'gloo'
+            # validation aid for 1-GPU boxes (scripts/check_dp2_shared_gpu.py): every rank on device 0, collectives over
+            # gloo (RCCL refuses two ranks on one device). Never set in production launches.
+            shared_gpu = use_cuda and os.environ.get('CRL_DEBUG_SHARED_GPU', '0') == '1'
+            if shared_gpu:
+                backend = 'gloo'
+            device_index = 0 if shared_gpu else self.local_rank
             if use_cuda:
-                torch.cuda.set_device(self.local_rank)  # before the RCCL communicator is created
+                torch.cuda.set_device(device_index)  # before the RCCL communicator is created
             if not dist.is_initialized():
                 if 'SLURM_PROCID' in os.environ:
                     dist.init_process_group(backend=backend, init_method=init_dist_url, world_size=init_world_size,
@@ -89,7 +95,7 @@ class DeviceEnv:
                     dist.init_process_group(backend=backend, init_method=init_dist_url)
             self.world_size = dist.get_world_size()
             self.global_rank = dist.get_rank()
-            self.device = torch.device('cuda:%d' % self.local_rank) if use_cuda else torch.device('cpu')
+            self.device = torch.device('cuda:%d' % device_index) if use_cuda else torch.device('cpu')
         else:
             if use_cuda:
                 self.device = torch.device('cuda' if init_device_index is None else f'cuda:{init_device_index}')

@@ -1,0 +1,87 @@
+"""Data-parallel equivalence check on a ONE-GPU box (the 8-GPU node is the driver's):
+  CRL_DEBUG_SHARED_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+      --master-port 29533 scripts/check_dp2_shared_gpu.py --out /tmp/dp2.pt
+  python scripts/check_dp2_shared_gpu.py --reference /tmp/dp2.pt
+The first command runs TaskCrullerPretrain on two ranks (both on cuda:0, collectives over gloo) through the bucketed
+asynchronous gradient reducer; the second runs ONE process with grad_accum_steps=2 over the same four batches -- the
+same average of two per-batch mean-loss gradients -- and compares parameters, AdamW state and losses."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def make_task(accum):
+    from tests.test_model_gpu import _register_test_archs, _cfg
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    _register_test_archs()
+    L, layers, img = 24, 2, (37, 50)
+    cfg = TaskCrullerPretrainCfg(num_intervals=4, num_warmup_intervals=1, eval_frequency=1000, dtype='bfloat16',
+                                 opt=OptimizationCfg(learning_rate=1e-3, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm',
+                                                     grad_accum_steps=accum),
+                                 model=_cfg('vit_test', img, 'RGB', layers, L))
+    torch.manual_seed(5)
+    env = DeviceEnv()
+    t = TaskCrullerPretrain(cfg, env)
+    t.train_setup(num_batches_per_interval=2 * accum)
+    t.train_interval_start()
+    return t, env
+
+
+def samples():
+    from oracle import ref_cpu as R
+    spec = R.ModelSpec('vit_test', 'bart_test', 2, 24, (37, 50), 3, vocab=50267)
+    return [R.synthetic_sample(spec, 2, seed=40 + i, ragged=True) for i in range(4)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out')
+    ap.add_argument('--reference')
+    a = ap.parse_args()
+    from tests.test_model_gpu import _register_test_archs
+    _register_test_archs()
+    ss = samples()
+    if a.reference:
+        t, env = make_task(accum=2)
+        assert env.world_size == 1
+        losses = []
+        for s in ss:
+            t.train_step(s)
+            losses.append(float(t.last_loss))
+        got = torch.load(a.reference)
+        ar = t.model.arena
+        for name, mine in (('p', ar.p), ('m', ar.m), ('v', ar.v)):
+            ref = got[name].to(mine.device)
+            err = float((mine - ref).abs().max()); scale = float(ref.abs().max())
+            print(f'{name}: max |dp2 - accum2| = {err:.3e} (max |value| {scale:.3e})')
+            assert err <= 2e-6 * max(scale, 1.0) + 1e-9, name
+        # per-step loss of the DP run = mean of the two ranks' losses = sum of the two accumulation micro-losses
+        dp_losses = got['losses']
+        acc_losses = [losses[0] + losses[1], losses[2] + losses[3]]
+        print('losses dp2', dp_losses, 'accum2', acc_losses)
+        assert all(abs(x - y) < 1e-5 * abs(y) for x, y in zip(dp_losses, acc_losses))
+        print('DP2 == ACCUM2: OK')
+        return
+    import torch.distributed as dist
+    t, env = make_task(accum=1)
+    assert env.world_size == 2, 'launch with torchrun --nproc-per-node 2'
+    losses = []
+    for k in range(2):
+        t.train_step(ss[2 * k + env.global_rank])
+        l = torch.tensor([float(t.last_loss)], dtype=torch.float64)
+        dist.all_reduce(l)
+        losses.append(float(l) / 2)
+    ar = t.model.arena
+    other = [torch.empty_like(ar.p) for _ in range(2)]
+    dist.all_gather(other, ar.p)
+    assert torch.equal(other[0], other[1]), 'ranks diverged'
+    if env.global_rank == 0:
+        torch.save({'p': ar.p.cpu(), 'm': ar.m.cpu(), 'v': ar.v.cpu(), 'losses': losses}, a.out)
+        print('dp2 run done: ranks identical, losses', losses)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
