@@ -1,2 +1,4 @@
 from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
+from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
+                                    TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 from .task_factory import TaskFactory

@@ -44,8 +44,8 @@ class TaskCrullerPretrainCfg(TaskTrainCfg):
 class ImagePreprocess:
     """ToTensor -> bicubic antialiased Resize(image_size) -> Normalize (ref :132-143), in plain torch (CPU, loader side)."""
 
-    def __init__(self, image_size, mean, std, num_chs):
-        self.image_size, self.num_chs = tuple(image_size), num_chs
+    def __init__(self, image_size, mean, std, num_chs, grayscale=False):
+        self.image_size, self.num_chs, self.grayscale = tuple(image_size), num_chs, grayscale
         self.mean = torch.tensor(mean if isinstance(mean, (tuple, list)) else [mean], dtype=torch.float32).view(-1, 1, 1)
         self.std = torch.tensor(std if isinstance(std, (tuple, list)) else [std], dtype=torch.float32).view(-1, 1, 1)
 
@@ -56,6 +56,8 @@ class ImagePreprocess:
             if a.ndim == 2:
                 a = a[:, :, None]
             img = torch.from_numpy(a).permute(2, 0, 1).float() / 255.0
+        if self.grayscale and img.shape[0] == 3:   # torchvision Grayscale(): ITU-R 601-2 luma
+            img = (0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2])[None]
         x = torch.nn.functional.interpolate(img[None], size=self.image_size, mode='bicubic', antialias=True, align_corners=False)[0]
         return (x - self.mean) / self.std
 
@@ -166,13 +168,19 @@ class TaskCrullerPretrain(TaskTrain):
             self.scaler.note_step(self.optimizer.state)
             self.scaler.update()
 
+    log_phase_name = 'train'
+
     def train_step(self, sample):
         image_input, text_input, text_target = sample
+        return self._train_step_shifted(image_input, text_input[:, :-1], text_target[:, 1:])
+
+    def _train_step_shifted(self, image_input, text_input, text_target):
+        """one micro-step on decoder inputs / labels that are already shifted against each other"""
         result = {}
         device = self.device_env.device
         image_input = image_input.to(device, non_blocking=True)
-        text_input = text_input[:, :-1].to(device, non_blocking=True)
-        text_target = text_target[:, 1:].to(device, non_blocking=True)
+        text_input = text_input.to(device, non_blocking=True)
+        text_target = text_target.to(device, non_blocking=True)
 
         accum_steps = self.cfg.opt.grad_accum_steps
         need_update = (self.interval_batch_idx + 1) % accum_steps == 0
@@ -189,7 +197,7 @@ class TaskCrullerPretrain(TaskTrain):
         # optimizer.zero_grad() is fused into the AdamW kernel (zero_grad=True above)
         if self.step % self.eval_frequency == 0 and self.monitor is not None:
             # the reference's train-time OCR metric call is broken (missing prompt_token arg): loss/lr only
-            self.monitor.log_step('train', step_idx=self.step, step_end_idx=self.num_intervals * self.num_steps_per_interval,
+            self.monitor.log_step(self.log_phase_name, step_idx=self.step, step_end_idx=self.num_intervals * self.num_steps_per_interval,
                                   interval=self.interval_idx, loss=loss.item(), lr=self.get_current_lr(), metrics=self.train_metrics)
         return result
 

@@ -1,15 +1,21 @@
-"""name -> (TaskCls, CfgCls) registry (ref: task/task_factory.py:44-79).  Only the pretrain task is on the
-hot path; the reference's fine-tune / eval entries are 'next' rows and raise a clear error."""
+"""name -> (TaskCls, CfgCls) registry (ref: task/task_factory.py:44-79).  The pretrain task is the hot path; the
+fine-tune tasks reuse its step; the reference's eval / xent entries are not built and raise a
+clear error."""
 from ..framework import DeviceEnv, Monitor
 from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
+from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
+                                    TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 
 _NOT_BUILT = ('cruller_eval_ocr', 'cruller_eval_rvlcdip', 'cruller_eval_cord', 'cruller_eval_docvqa', 'donut_eval_ocr',
-              'cruller_finetune_rvlcdip', 'cruller_finetune_cord', 'cruller_finetune_docvqa', 'cruller_finetune_xent')
+              'cruller_finetune_xent')
 
 
 class TaskFactory:
     TASK_CLASS_REGISTRY = {
         'cruller_pretrain': (TaskCrullerPretrain, TaskCrullerPretrainCfg),
+        'cruller_finetune_rvlcdip': (TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg),
+        'cruller_finetune_cord': (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg),
+        'cruller_finetune_docvqa': (TaskCrullerFinetuneDOCVQA, TaskCrullerFinetuneDOCVQACfg),
     }
 
     @classmethod
@@ -17,7 +23,7 @@ class TaskFactory:
         task_name = task_name.lower()
         if task_name in _NOT_BUILT:
             raise NotImplementedError(f'task {task_name!r} exists in the reference but is outside the MI355X hot-path scope '
-                                      '(SURVEY.md §8f); only cruller_pretrain is built')
+                                      '(SURVEY.md §8f); built: ' + ', '.join(cls.TASK_CLASS_REGISTRY))
         if task_name not in cls.TASK_CLASS_REGISTRY:
             raise ValueError(f'Unknown task type: {task_name}. Available tasks are {list(cls.TASK_CLASS_REGISTRY.keys())}')
         task_cls, task_cfg = cls.TASK_CLASS_REGISTRY[task_name]

@@ -1,1 +1,2 @@
 from .name_utils import _natural_key, clean_name
+from .json_utils import json2token, token2json

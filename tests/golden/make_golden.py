@@ -163,6 +163,74 @@ def gen_preprocess():
     print('g3', len(cases), 'cases')
 
 
+# ------------------------------------------------------------------ G6: fine-tune glue (json2token, prompt masking)
+def _ref_function(path, name, cls=None, extra_globals=None):
+    """compile ONE function (or one method of `cls`) of a reference file without importing the file's other
+    dependencies (zss / nltk / timm are not installed here); the function's own body runs unmodified"""
+    import ast
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    fn = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    g = {'__builtins__': __builtins__, 'torch': torch, 're': __import__('re')}
+    g.update(extra_globals or {})
+    exec(compile(mod, os.path.join(REF, path), 'exec'), g)
+    return g[name]
+
+
+def gen_finetune():
+    json2token = _ref_function('utils/json_utils.py', 'json2token')
+    token2json = _ref_function('utils/json_utils.py', 'token2json')
+    specials = ['<s>', '</s>', '<pad>', '<sep/>', '<yes/>', '<no/>']
+    objs = [
+        {'menu': [{'nm': 'latte', 'cnt': '2', 'price': '9.0'}, {'nm': 'tea', 'cnt': '1'}], 'total': {'total_price': '11.0'}},
+        {'menu': {'nm': 'single', 'price': 3}, 'sub_total': {'subtotal_price': '3', 'tax_price': ['0.1', '0.2']}},
+        {'text_sequence': 'already a sequence'},
+        {'answer': 'yes', 'flag': 'no', 'other': 'maybe'},
+        ['a', 'b', {'k': 'v'}],
+        'leaf',
+    ]
+    cases = []
+    for o in objs:
+        for sort_keys in (False, True):
+            out = json2token(o, specials, [], True, sort_keys)
+            text = out if isinstance(out, str) else out[0]
+            toks = [] if isinstance(out, str) else sorted(out[1])
+            back = token2json(text, added_vocab={t: i for i, t in enumerate(specials)})
+            cases.append(dict(obj=o, sort_json_key=sort_keys, specials=specials, text=text, key_tokens=toks, token2json=back))
+    # prompt masking: the method body of the three fine-tune tasks, bound to a stub with their token ids
+    from pixparse_amd.tokenizers import ByteBartTokenizer   # byte-level stand-in with BART's special ids
+    tok = ByteBartTokenizer()
+    tok.add_special_tokens({'additional_special_tokens': ['<sep/>', '<s_pretrain>', '<s_docvqa>', '<s_answer>', '<s_rvlcdip>',
+                                                          '<s_question>', '</s_question>', '</s_answer>', '<letter/>']})
+    masks = []
+    for path, cls, prompt_end, seqs in (
+            ('task/task_cruller_finetune_RVLCDIP.py', 'TaskCrullerFinetuneRVLCDIP', '<s_rvlcdip>', [('<s_rvlcdip><letter/></s>', 5)]),
+            ('task/task_cruller_finetune_docvqa.py', 'TaskCrullerFinetuneDOCVQA', '<s_answer>',
+             [('<s_docvqa><s_question>who?</s_question><s_answer>me</s_answer></s>', 32),
+              ('<s_docvqa><s_question>a much longer question text</s_question><s_answer>x</s_answer></s>', 24)]),
+            ('task/task_cruller_finetune_CORD.py', 'TaskCrullerFinetuneCORD', '<s_pretrain>', [('<s_pretrain>abc</s>', 8)])):
+        fn = _ref_function(path, 'text_input_to_target', cls=cls)
+
+        class _Self:
+            pass
+        me = _Self()
+        me.tokenizer = _Self()
+        me.tokenizer.trunk = tok
+        me.prompt_end_token = prompt_end
+        for text, L in seqs:
+            ids = tok(text, add_special_tokens=False, return_tensors='pt', max_length=L, padding='max_length', truncation=True).input_ids[0]
+            tgt = fn(me, ids)
+            masks.append(dict(task=cls, prompt_end=prompt_end, text=text, max_length=L, ids=ids.tolist(), target=tgt.tolist()))
+    with open(os.path.join(HERE, 'g6_finetune.json'), 'w') as f:
+        json.dump(dict(json2token=cases, text_input_to_target=masks, added_tokens=tok.added), f, indent=1)
+    print('g6', len(cases), 'json2token cases,', len(masks), 'masking cases')
+
+
+
 # ------------------------------------------------------------------ G4: encoders
 def randomise(model, seed):
     gen = torch.Generator().manual_seed(seed)
@@ -332,3 +400,4 @@ if __name__ == '__main__':
     gen_swin('g4_swin_shift', 64, 64, (2, 2), (2, 4), 4)       # 16x16 -> 8x8, shifted windows in both stages
     gen_swin('g4_swin_clamp', 64, 32, (2, 2), (2, 4), 4)       # 16x8 -> 8x4: window == min side -> shift 0
     gen_optim()
+    gen_finetune()

@@ -230,3 +230,49 @@ def test_resume_continues_identically(dev):
         b.train_step(s)
         lb.append(float(b.last_loss))
     assert all(abs(x - y) < 1e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
+
+
+def test_finetune_rvlcdip_steps_vs_oracle_trainer(dev):
+    """f-3: cruller_finetune_rvlcdip through TaskFactory -- pretrain checkpoint loaded, 19 tokens added, collate_fn on
+    uint8 pages, dict samples, 4-token decoder sequences; loss trajectory and updated weights vs the oracle trainer"""
+    import numpy as np
+    from oracle import ref_cpu as R
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg, TaskFactory
+    _register_test_archs()
+    layers, img = 2, (37, 50)
+    model_cfg = _cfg('vit_test', img, 'L', layers, 512)
+    torch.manual_seed(3)
+    pre = TaskCrullerPretrain(TaskCrullerPretrainCfg(dtype='bfloat16', model=model_cfg), DeviceEnv())
+    ckpt = {'module.' + k: v.clone() for k, v in pre.model.state_dict().items()}     # a DDP pretrain checkpoint, vocab 50267
+    args = dict(num_intervals=2, num_warmup_intervals=0, eval_frequency=1000, dtype='bfloat16', model=model_cfg,
+                opt=OptimizationCfg(learning_rate=5e-4, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm'))
+    task, _ = TaskFactory.create_task('cruller_finetune_rvlcdip', args, DeviceEnv(), None)
+    task.state_dict = ckpt
+    task.resume = True
+    torch.manual_seed(4)                                         # the 19 new embedding rows
+    task.train_setup(num_batches_per_interval=2)
+    V = task.vocab_size
+    assert V == 50286
+    params = {k: v.detach().cpu().clone() for k, v in task.model.state_dict().items() if not k.endswith('lm_head.weight')}
+    for k, v in ckpt.items():                                    # everything but the grown embedding equals the checkpoint
+        k = k[7:]
+        if k in params and 'embed_tokens' not in k:
+            assert torch.equal(params[k], v.cpu()), k
+    spec = R.ModelSpec('vit_test', 'bart_test', layers, 512, img, 1, vocab=V)
+    tr = R.OracleTrainer(spec, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, clip_grad=1.0, accum_steps=1, warmup_t=0, t_initial=4)
+    task.train_interval_start()
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        batch = [{'image': rng.randint(0, 256, size=(60 + 7 * j, 45 + 5 * j, 3)).astype(np.uint8), 'label': int(rng.randint(16))} for j in range(3)]
+        sample = task.collate_fn(batch)
+        assert sample['label'].shape == (3, 4)
+        # the oracle shifts by itself: give it the unshifted sequences the collator built
+        full = torch.stack([task._tokenize(task._sequence_for(it)) for it in batch])
+        full_t = torch.stack([task.text_input_to_target(t) for t in full])
+        lo = tr.train_step((sample['image'], full, full_t))
+        task.train_step(sample)
+        lh = float(task.last_loss)
+        assert abs(lh - lo) / abs(lo) < 2e-3, (i, lh, lo)
+    k = 'text_decoder.trunk.model.decoder.embed_tokens.weight'
+    assert rel(task.model.state_dict()[k][50267:], tr.params[k].detach()[50267:]) < 2e-3     # the new class-token rows learn
