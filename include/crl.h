@@ -58,6 +58,15 @@ int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
                   const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream);
 
+/* Skinny linear layer for generation (replaces nn.Linear / F.linear on [B, 1, K] decode-step activations inside
+ * transformers' BartDecoderLayer, reached from the reference through models/text_decoder_hf.py:39-45 and
+ * utils/ocr_utils.py:181-187):  out[M, N] = epilogue(x[M, K] @ W[N, K]^T + bias),  1 <= M <= 16, N % 4 == 0, K % 8 == 0.
+ * epilogue: CRL_EPI_BF16 (bf16 out), CRL_EPI_BF16_GELU (bf16 GELU(out)), CRL_EPI_F32_RESID (fp32 out = resid + bf16-rounded
+ * result). Same arithmetic as crl_gemm_bf16 (fp32 accumulate, bias rounded to bf16); HBM-bound on W. */
+int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
+                           int64_t ldw, const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
+                           void* stream);
+
 /* column sums of a bf16 matrix into fp32 (bias gradients): out[n] (+)= sum_m X[m,n].
  * ws: >= crl_colsum_ws_bytes(N) bytes of scratch. */
 size_t crl_colsum_ws_bytes(int64_t N);

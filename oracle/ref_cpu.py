@@ -430,6 +430,35 @@ def cruller_forward(p: Dict[str, Tensor], spec: ModelSpec, image: Tensor, text_i
                                 prefix='text_decoder.trunk.', fast_attn=fast_attn)
 
 
+def encode_image(p: Dict[str, Tensor], spec: ModelSpec, image: Tensor, policy: str = 'bf16') -> Tensor:
+    """model.image_encoder(image) (task_cruller_eval_ocr.py) -> [B, S, D]"""
+    if spec.enc_kind == 'swin':
+        return swin_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.')
+    return vit_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.')
+
+
+def greedy_generate(p: Dict[str, Tensor], spec: ModelSpec, encoder_outputs: Tensor, prompt_id: int, eos_id: int,
+                    max_recursion_length: int, policy: str = 'bf16', return_logits: bool = False):
+    """utils/ocr_utils.py:165-197 get_generated_tokens with use_sample=False: the WHOLE decoder is re-run on the growing
+    sequence for every new token (no KV cache); samples that already produced eos keep being extended until all have;
+    the token that completes the last sample is not appended."""
+    B = encoder_outputs.shape[0]
+    input_ids = torch.full((B, 1), prompt_id, dtype=torch.int64)
+    finished = torch.zeros(B, dtype=torch.bool)
+    steps = []
+    for _ in range(max_recursion_length):
+        logits = bart_decoder_forward(p, spec.dec_arch, spec.n_layers, input_ids, encoder_outputs, policy,
+                                      prefix='text_decoder.trunk.')
+        nxt = logits[:, -1, :]
+        steps.append(nxt.float())
+        next_id = torch.argmax(nxt.float(), dim=-1, keepdim=True)
+        finished |= next_id.squeeze(-1) == eos_id
+        if finished.all():
+            break
+        input_ids = torch.cat([input_ids, next_id], dim=-1)
+    return (input_ids, steps) if return_logits else input_ids
+
+
 def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
     """nn.CrossEntropyLoss(ignore_index=-100): fp32 log-softmax, mean over non-ignored."""
     return F.cross_entropy(logits.float().view(-1, logits.shape[-1]), target.reshape(-1),

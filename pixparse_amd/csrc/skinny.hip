@@ -1,0 +1,97 @@
+// Skinny linear layer for decode-time projections (include/crl.h: crl_linear_skinny_bf16):
+//   out[m, n] = epilogue( sum_k x[m, k] * W[n, k] + bias[n] ),   M <= 16 rows (one per sequence being generated).
+// HBM-bound on W (every weight byte is read once, 2 FLOP per 2 bytes per row): no LDS staging, no tile reuse to win --
+// a workgroup owns 16 output columns, its four waves split K and stream W straight from global memory as the A operand
+// of v_mfma_f32_16x16x32_bf16 (lane -> column n0 + (lane & 15), 8 consecutive k at 8 (lane >> 4)); the <= 16 rows of x
+// are the B operand (L2-resident, re-read per workgroup). The four partial 16x16 tiles are summed through LDS in wave
+// order (deterministic) and wave 0 applies the same epilogues as the GEMM (bias rounded to bf16, fp32 accumulate,
+// bf16 output / exact-erf GELU / fp32 residual add).
+#include "common.h"
+
+namespace {
+
+struct SkArgs {
+  const u16* x; const u16* W; const float* bias; void* out; const float* resid;
+  int64_t ldx, ldw, ldo, ldr;
+  int M, N, K;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const SkArgs a) {
+  __shared__ f32x4 red[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int ksteps = (a.K + 31) / 32;                 // 32-wide k steps, split over the four waves
+  const int per = (ksteps + 3) / 4;
+  const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+  const bool col_ok = n0 + i < a.N, row_ok = i < a.M;
+  const u16* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.ldw + 8 * kq;
+  const u16* xp = a.x + (int64_t)min(i, a.M - 1) * a.ldx + 8 * kq;
+  const bf16x8 zero = {};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
+    const int k = 32 * s + 8 * kq;
+    const bool k_ok = k < a.K;                          // K % 8 == 0: a chunk is entirely in or out
+    const bf16x8 wf = (col_ok && k_ok) ? *reinterpret_cast<const bf16x8*>(wp + 32 * s) : zero;
+    const bf16x8 xf = (row_ok && k_ok) ? *reinterpret_cast<const bf16x8*>(xp + 32 * s) : zero;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);   // D[row = column n (A), col = row m (B)]
+  }
+  if (wave) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const f32x4 o = red[w][lane];
+    acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
+  }
+  const int m = lane & 15, n = n0 + 4 * (lane >> 4);   // this lane: row m, columns n .. n+3
+  if (m >= a.M || n >= a.N) return;                     // N % 4 == 0
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (a.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+    v[0] += round_bf(b.x); v[1] += round_bf(b.y); v[2] += round_bf(b.z); v[3] += round_bf(b.w);
+  }
+  if constexpr (EPI == CRL_EPI_BF16) {
+    *reinterpret_cast<uint2*>((u16*)a.out + (int64_t)m * a.ldo + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = gelu_f(round_bf(v[r]));
+    *reinterpret_cast<uint2*>((u16*)a.out + (int64_t)m * a.ldo + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+  } else {   // CRL_EPI_F32_RESID
+    const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)m * a.ldr + n);
+    *reinterpret_cast<float4*>((float*)a.out + (int64_t)m * a.ldo + n) =
+        float4{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
+  }
+}
+
+}  // namespace
+
+extern "C" int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
+                                      int64_t ldw, const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
+                                      void* stream) {
+  const char* who = "crl_linear_skinny_bf16";
+  CRL_CHECK(x && W && out, "%s: null pointer", who);
+  CRL_CHECK(M >= 1 && M <= 16, "%s: M = %d rows (1..16 supported; use crl_gemm_bf16 beyond)", who, M);
+  CRL_CHECK(N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0, "%s: need N %% 4 == 0 and K %% 8 == 0 (N=%lld K=%lld)", who, (long long)N, (long long)K);
+  CRL_CHECK(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && ldo >= N && ldo % 4 == 0, "%s: bad leading dimensions", who);
+  CRL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0, "%s: x and W must be 16-byte aligned", who);
+  CRL_CHECK(((uintptr_t)out % (epilogue == CRL_EPI_F32_RESID ? 16 : 8)) == 0, "%s: out must be 8-byte (bf16) / 16-byte (fp32) aligned", who);
+  CRL_CHECK(N < (1ll << 31) - 16 && K < (1ll << 31) - 32, "%s: extent too large", who);
+  SkArgs a{(const u16*)x, (const u16*)W, bias, out, resid, ldx, ldw, ldo, ldr, M, (int)N, (int)K};
+  const unsigned grid = (unsigned)((N + 15) / 16);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (epilogue == CRL_EPI_BF16) linear_skinny_kernel<CRL_EPI_BF16><<<grid, 256, 0, s>>>(a);
+  else if (epilogue == CRL_EPI_BF16_GELU) linear_skinny_kernel<CRL_EPI_BF16_GELU><<<grid, 256, 0, s>>>(a);
+  else if (epilogue == CRL_EPI_F32_RESID) {
+    CRL_CHECK(resid && ldr >= N && ldr % 4 == 0 && ((uintptr_t)resid % 16) == 0, "%s: F32_RESID needs an aligned residual", who);
+    linear_skinny_kernel<CRL_EPI_F32_RESID><<<grid, 256, 0, s>>>(a);
+  } else {
+    crl_set_error("%s: epilogue %d not supported (BF16, BF16_GELU, F32_RESID)", who, epilogue);
+    return -1;
+  }
+  CRL_LAUNCH_CHECK(who);
+  return 0;
+}

@@ -19,6 +19,7 @@ SIGNATURES = {
     'crl_gemm_ws_bytes': (Z, [I, I, L, L, L]),
     'crl_gemm_set_policy': (I, [I]),
     'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, P, Z, P]),
+    'crl_linear_skinny_bf16': (I, [I, I, L, L, P, L, P, L, P, P, L, P, L, P]),
     'crl_colsum_ws_bytes': (Z, [L]),
     'crl_colsum_bf16': (I, [P, L, L, L, P, I, P, P]),
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),

@@ -481,6 +481,68 @@ class BartEngine(_Base):
         ops.linear_fwd(hb, self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D), None, logits)
         return logits
 
+    # ------------------------------------------------------------------ generation with a KV cache
+    def _lin(self, x, w, b, out, epi=ops.EPI_BF16, resid=None):
+        """decode rows go through the skinny kernel (weights read once), prefill-sized inputs through the GEMM"""
+        if x.shape[0] <= ops.SKINNY_MAX_ROWS:
+            ops.linear_skinny(x, w, b, out, epi, resid=resid)
+        else:
+            ops.linear_fwd(x, w, b, out, epi, resid=resid)
+
+    def decode_begin(self, enc16: torch.Tensor, B: int, S: int, max_len: int):
+        """enc16 bf16 [B*S, D].  Projects the encoder states to every layer's cross-attention K/V once and lays out
+        empty self-attention K/V caches [B, max_len, 2D] (k | v per row, read by the attention kernel as strided views)."""
+        assert max_len <= self.max_pos, f'max_len {max_len} exceeds the {self.max_pos} learned positions'
+        dp, D = self.DP, self.D
+        self.gen = dict(B=B, S=S, max_len=max_len, t=0)
+        for i in range(self.L):
+            lp = dp + f'layers.{i}.'
+            kv2 = self.buf(f'gen.l{i}.kv2', (B * S, 2 * D), BF16)
+            ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
+            self.buf(f'gen.l{i}.kvc', (B, max_len, 2 * D), BF16)
+
+    def decode_step(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids [B, 1] = the token at position t (t = number of tokens fed so far) -> logits bf16 [B, Vp] for position t+1.
+        Same layer arithmetic as forward(); the self-attention sees the cached keys 0..t, nothing is recomputed."""
+        g = self.gen
+        B, S, t = g['B'], g['S'], g['t']
+        assert ids.shape == (B, 1) and t < g['max_len']
+        dp, D, F_, H = self.DP, self.D, self.F, self.heads
+        eps = self.a['ln_eps']
+        scale = (D // H) ** -0.5
+        emb = self.buf('gen.emb', (B, D), F32)
+        ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2 + t)
+        h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'gen.ln_emb', eps, want_f32=True, want_bf16=True)
+        for i in range(self.L):
+            lp, k = dp + f'layers.{i}.', f'gen.l{i}'
+            kvc = self.bufs.t[self.tag + '.' + k + '.kvc']
+            q = self.buf(k + '.q', (B, D), BF16)
+            self._lin(hb, self.fw('w', lp, 'self_attn', 'q_proj', 1), self.fb('p', lp, 'self_attn', 'q_proj', 1), q)
+            self._lin(hb, self.fw('w', lp, 'self_attn', 'k_proj', 2), self.fb('p', lp, 'self_attn', 'k_proj', 2), kvc[:, t, :])
+            o1 = self.buf(k + '.o1', (B, D), BF16)
+            lse = self.buf(k + '.lse', (B, H, 1), F32)
+            ops.attn_fwd(q.view(B, 1, D), kvc[:, :t + 1, 0:D], kvc[:, :t + 1, D:], o1.view(B, 1, D), lse, H, scale, False)
+            t1 = self.buf(k + '.t1', (B, D), F32)
+            self._lin(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
+            h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
+            q2 = self.buf(k + '.q2', (B, D), BF16)
+            self._lin(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
+            kv3 = self.bufs.t[self.tag + '.' + k + '.kv2'].view(B, S, 2 * D)
+            o2 = self.buf(k + '.o2', (B, D), BF16)
+            ops.attn_fwd(q2.view(B, 1, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, 1, D), lse, H, scale, False)
+            t2 = self.buf(k + '.t2', (B, D), F32)
+            self._lin(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
+            h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
+            act = self.buf(k + '.act', (B, F_), BF16)
+            self._lin(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU)
+            t3 = self.buf(k + '.t3', (B, D), F32)
+            self._lin(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, EPI_F32_RESID, resid=h2)
+            h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, k + '.ln3', eps, True, True)
+        logits = self.buf('gen.logits', (B, self.Vp), BF16)
+        self._lin(hb, self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D), None, logits)
+        g['t'] = t + 1
+        return logits
+
     def backward(self, dlogits: torch.Tensor, enc16: torch.Tensor, denc: torch.Tensor, on_layer_done=None):
         """dlogits bf16 [M, Vp] (pad columns zero); accumulates the encoder-output gradient into denc (fp32 [B*S, D],
         must be zeroed by the caller)."""

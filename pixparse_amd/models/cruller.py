@@ -38,6 +38,10 @@ class _DecoderTrunk(_Container):
 
 
 class _TextDecoder(_Container):
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, '_owner', owner)
+
     def prepare_inputs_for_inference(self, input_ids, encoder_outputs, pad_token_id, past_key_values=None, past=None,
                                      use_cache=None, attention_mask=None):
         """ref: models/text_decoder_hf.py:47-78"""
@@ -48,6 +52,29 @@ class _TextDecoder(_Container):
             input_ids = input_ids[:, -1:]
         return {'input_ids': input_ids, 'attention_mask': attention_mask, 'past_key_values': past_key_values,
                 'use_cache': use_cache, 'encoder_hidden_states': encoder_outputs}
+
+
+    def forward(self, input_ids, encoder_hidden_states, attention_mask=None, past_key_values=None, use_cache=None, **_):
+        """ref models/text_decoder_hf.py:39-45: the full (uncached) decoder over input_ids [B, T] -> .logits [B, T, V].
+        Generation proper goes through Cruller.decode_begin / decode_step (KV cache); this is the drop-in for callers
+        that re-run the decoder on the whole prefix like utils/ocr_utils.py:181-187."""
+        owner = self._owner
+        _, dec, _ = owner._ensure_engines()
+        B, S, D = encoder_hidden_states.shape
+        enc16 = encoder_hidden_states.reshape(B * S, D).to(torch.bfloat16).contiguous()
+        T = input_ids.shape[1]
+        logits = dec.forward(input_ids.contiguous(), enc16, S)
+        return CausalLMOutput(logits=logits.view(B, T, dec.Vp)[:, :, :owner.vocab_size], past_key_values=None)
+
+
+class _ImageEncoder(_Container):
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, '_owner', owner)
+
+    def forward(self, image_input):
+        """ref models/image_encoder_timm.py forward: features [B, S, D]"""
+        return self._owner.encode_image(image_input)
 
 
 class CausalLMOutput(dict):
@@ -114,10 +141,10 @@ class Cruller(nn.Module):
         # module tree mirroring the reference checkpoint keys
         self._modules.pop('image_encoder', None)
         self._modules.pop('text_decoder', None)
-        self.image_encoder = _Container()
+        self.image_encoder = _ImageEncoder(self)
         self.image_encoder.trunk = _Container()
         self.image_encoder.trunk.pretrained_cfg = {'mean': self.enc_arch['mean'], 'std': self.enc_arch['std']}
-        self.text_decoder = _TextDecoder()
+        self.text_decoder = _TextDecoder(self)
         self.text_decoder.trunk = _DecoderTrunk(self)
         self._pmap = OrderedDict()
         for name in arena.entries:
@@ -221,6 +248,25 @@ class Cruller(nn.Module):
         logits = dec.forward(text_input.contiguous(), enc16, enc.out_tokens())
         return CausalLMOutput(logits=logits.view(B, T, dec.Vp)[:, :, :self.vocab_size],
                               encoder_last_hidden_state=enc32.view(B, enc.out_tokens(), -1))
+
+    # ------------------------------------------------------------------ generation
+    def encode_image(self, image_input: torch.Tensor) -> torch.Tensor:
+        """what the reference's eval tasks call `model.image_encoder(image)`: last hidden states fp32 [B, S, D]"""
+        enc, _, _ = self._ensure_engines()
+        enc32, _ = self.encode(image_input)
+        return enc32.view(image_input.shape[0], enc.out_tokens(), -1)
+
+    def decode_begin(self, encoder_outputs: torch.Tensor, max_len: int):
+        """encoder_outputs [B, S, D] (fp32 or bf16): builds the cross-attention K/V and empty self-attention caches"""
+        _, dec, _ = self._ensure_engines()
+        B, S, D = encoder_outputs.shape
+        enc16 = encoder_outputs.reshape(B * S, D).to(torch.bfloat16).contiguous()
+        dec.decode_begin(enc16, B, S, int(max_len))
+
+    def decode_step(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """input_ids [B, 1]: the next token of every sequence -> next-token logits bf16 [B, V]"""
+        _, dec, _ = self._ensure_engines()
+        return dec.decode_step(input_ids.contiguous())[:, :self.vocab_size]
 
     def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0):
         """forward + shifted-token cross-entropy; leaves d(loss*grad_mul)/dlogits in the logits buffer.

@@ -53,6 +53,18 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], o
          aux.stride(0) if aux is not None else 0, resid, resid.stride(0) if resid is not None else 0)
 
 
+SKINNY_MAX_ROWS = 16
+
+
+def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16,
+                  resid: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+    """decode-time linear_fwd for M <= 16 rows (crl_linear_skinny_bf16): every weight byte read once, no tiles"""
+    M, K = x.shape
+    N = n if n is not None else w.shape[0]
+    hip.call('crl_linear_skinny_bf16', epi, M, N, K, _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+             _p(resid), resid.stride(0) if resid is not None else 0, _stream())
+
+
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epi: int = EPI_BF16,
                  aux: Optional[torch.Tensor] = None, k: Optional[int] = None) -> None:
     """out[M, Kin] = dy[M, N] @ w[N, Kin]; contraction over N (= dy.shape[1])."""

@@ -63,6 +63,34 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     close(out, x.float() @ w.float().t(), 1e-2, 1e-2, 'no bias')
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 1024, 1024), (2, 264, 200), (7, 4096, 1024), (16, 1024, 4096), (3, 50304, 128), (5, 20, 40)])
+def test_linear_skinny_vs_gemm_semantics(dev, M, N, K):
+    """crl_linear_skinny_bf16 (decode-time projections): same arithmetic as the GEMM epilogues, strided output rows"""
+    from pixparse_amd import ops
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    ref = x.float() @ w.float().t() + bias.to(BF16).float()
+    big = torch.zeros(M, 3, N, dtype=BF16, device=dev)                # rows of a KV cache: out.stride(0) = 3N
+    ops.linear_skinny(x, w, bias, big[:, 1, :])
+    close(big[:, 1, :], ref, 1e-2, 1e-2, 'skinny EPI_BF16')
+    assert float(big[:, 0, :].abs().max()) == 0 and float(big[:, 2, :].abs().max()) == 0
+    act = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_skinny(x, w, bias, act, ops.EPI_BF16_GELU)
+    close(act, torch.nn.functional.gelu(ref.to(BF16).float()), 1e-2, 2e-3, 'skinny GELU')
+    resid = rnd((M, N), dev, 1.0, 4)
+    y = resid.clone()
+    ops.linear_skinny(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+    close(y, resid + ref.to(BF16).float(), 1e-2, 2e-2, 'skinny F32_RESID')
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_skinny(x, w, None, out)
+    close(out, x.float() @ w.float().t(), 1e-2, 1e-2, 'skinny no bias')
+    if M <= 16 and N >= 128 and K % 64 == 0:                           # bit-identical to the tiled GEMM? (different summation order: close)
+        g = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, None, g)
+        close(out, g, 8e-3, 8e-3, 'skinny vs gemm')
+
+
 @pytest.mark.parametrize('M,N,K', [(300, 288, 192), (130, 96, 288), (1000, 544, 1024)])
 def test_gemm_nn_dgrad(dev, M, N, K):
     """dx[M, K] = dy[M, N] @ w[N, K] (+ fused GELU backward)"""

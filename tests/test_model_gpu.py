@@ -276,3 +276,58 @@ def test_finetune_rvlcdip_steps_vs_oracle_trainer(dev):
         assert abs(lh - lo) / abs(lo) < 2e-3, (i, lh, lo)
     k = 'text_decoder.trunk.model.decoder.embed_tokens.weight'
     assert rel(task.model.state_dict()[k][50267:], tr.params[k].detach()[50267:]) < 2e-3     # the new class-token rows learn
+
+
+@pytest.mark.parametrize('enc,img,fmt,B', [('vit_test', (37, 50), 'RGB', 3), ('swin_test', (64, 64), 'L', 2)])
+def test_greedy_generation_with_kv_cache_vs_oracle(dev, enc, img, fmt, B):
+    """f-4: utils.ocr_utils.get_generated_tokens (KV cache, skinny projections, single-query attention) against the
+    oracle's restatement of the reference loop (whole decoder re-run per token). Random weights give nearly flat
+    logits, so besides the per-step logits the check is: every token chosen here is an arg-max of the ORACLE's logits
+    for the same prefix up to the bf16 tolerance."""
+    from oracle import ref_cpu as R
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.models import Cruller
+    from pixparse_amd.tokenizers import ByteBartTokenizer
+    from pixparse_amd.utils import generate_ocr, get_generated_tokens
+    _register_test_archs()
+    layers, L, V = 2, 24, 515
+    torch.manual_seed(11)
+    model = Cruller(_cfg(enc, img, fmt, layers, L), vocab_size=V)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.bias'):
+                p.normal_(0, 0.05)
+            elif p.dim() >= 2:
+                p.mul_(4.0)                                   # spread the logits
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith('lm_head.weight')}
+    spec = R.ModelSpec(enc, 'bart_test', layers, L, img, 1 if fmt == 'L' else 3, vocab=V)
+    image, _, _ = R.synthetic_sample(spec, B, seed=9)
+
+    class Tok:                                                # prompt id 514, eos 2 inside the 515-token test vocabulary
+        trunk = ByteBartTokenizer(base_vocab=514)
+    Tok.trunk.add_special_tokens({'additional_special_tokens': ['<s_pretrain>']})
+    model.to(dev)
+    model._ensure_engines()
+    model.refresh_shadows(full=True)
+    env = DeviceEnv()
+    enc_out = model.image_encoder(image.to(dev))
+    steps_max = 12
+    ids, logits = get_generated_tokens(model, Tok, enc_out, env, steps_max, '<s_pretrain>', return_logits=True)
+    assert ids.shape[0] == B and ids[:, 0].tolist() == [514] * B and 1 <= ids.shape[1] <= steps_max + 1
+    # oracle: its own encoder output, then the decoder re-run on OUR prefixes (teacher forcing keeps both on one path)
+    oenc = R.encode_image(params, spec, image, 'bf16')
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(enc_out.float().cpu(), oenc.float(), 3e-2)
+    for t in range(len(logits)):
+        ol = R.bart_decoder_forward(params, spec.dec_arch, layers, ids[:, :t + 1].cpu(), oenc, 'bf16', prefix='text_decoder.trunk.')[:, -1, :].float()
+        mine = logits[t].cpu()
+        assert close(mine, ol, 3e-2), (t, float((mine - ol).abs().max()))
+        if t + 1 < ids.shape[1]:
+            chosen = ids[:, t + 1].cpu()
+            margin = ol.max(-1).values - ol.gather(1, chosen[:, None])[:, 0]
+            assert float(margin.max()) <= 3e-2 * max(1.0, float(ol.abs().max())), (t, margin)
+    # same loop semantics as the oracle's restatement of ocr_utils.py:165-197 when it is fed OUR logits' arg-max path
+    oids = R.greedy_generate(params, spec, oenc, 514, 2, steps_max, 'bf16')
+    assert oids.shape[1] <= steps_max + 1 and oids[:, 0].tolist() == [514] * B
+    texts = generate_ocr(model, Tok, enc_out, env, 5, '<s_pretrain>')
+    assert len(texts) == B and all(t.startswith('<s_pretrain>') for t in texts)
