@@ -144,19 +144,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// sum of the per-block partials: 64 columns per workgroup, 4 row groups of partial blocks, LDS combine
+// sum of the per-block partials: 16 columns per workgroup x 16 groups of partial blocks (128+ workgroups for D = 1024
+// instead of 32), four independent accumulators per thread so the strided loads overlap, fixed-order LDS combine
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int acc) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (idx < 2 * D)
-    for (int b = rg; b < nblk; b += 4) s += ws[(size_t)b * 2 * D + idx];
-  red[rg][c] = s;
+  __shared__ float red[16][16];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < 2 * D) {
+    const float* p = ws + idx;
+    const size_t st = (size_t)2 * D;
+    int b = rg;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += p[(size_t)b * st]; s1 += p[(size_t)(b + 16) * st]; s2 += p[(size_t)(b + 32) * st]; s3 += p[(size_t)(b + 48) * st];
+    }
+    for (; b < nblk; b += 16) s0 += p[(size_t)b * st];
+  }
+  red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg != 0 || idx >= 2 * D) return;
-  s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += red[r][c];
   float* base = idx < D ? dgamma : dbeta;
   if (!base) return;
   float* dst = base + (idx < D ? idx : idx - D);
@@ -374,7 +384,7 @@ extern "C" int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const
                                                              dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws);
   CRL_LAUNCH_CHECK("crl_layernorm_bwd");
   if (dgamma || dbeta) {
-    ln_bwd_reduce<<<blocks_for(2 * D, 64), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad);
+    ln_bwd_reduce<<<blocks_for(2 * D, 16), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad);
     CRL_LAUNCH_CHECK("crl_layernorm_bwd(reduce)");
   }
   return 0;
