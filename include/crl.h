@@ -58,14 +58,27 @@ int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
                   const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream);
 
+/* Single-query attention over a KV cache (generation; replaces F.scaled_dot_product_attention inside transformers'
+ * BartAttention for a [B, 1, D] query, reference utils/ocr_utils.py:181-187 -> text_decoder_hf.py:39-45):
+ * q [B, H*64] (row stride q_bs), k / v [B, Nk, H*64] strided views (batch stride, row stride in elements), o [B, H*64]
+ * bf16. Keys are split over workgroups (HBM-bound); ws >= crl_attn_decode_ws_bytes(B, H, Nk) bytes of scratch.
+ * nk_minus1_dev (optional, device int): the valid prefix is *nk_minus1_dev + 1 keys and Nk is the cache capacity -- lets
+ * one captured hipGraph serve every step of the generation loop. */
+size_t crl_attn_decode_ws_bytes(int B, int H, int Nk);
+int crl_attn_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
+                    int64_t v_rs, void* o, int64_t o_bs, int B, int H, int Nk, float scale, const int* nk_minus1_dev,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* Skinny linear layer for generation (replaces nn.Linear / F.linear on [B, 1, K] decode-step activations inside
  * transformers' BartDecoderLayer, reached from the reference through models/text_decoder_hf.py:39-45 and
  * utils/ocr_utils.py:181-187):  out[M, N] = epilogue(x[M, K] @ W[N, K]^T + bias),  1 <= M <= 16, N % 4 == 0, K % 8 == 0.
  * epilogue: CRL_EPI_BF16 (bf16 out), CRL_EPI_BF16_GELU (bf16 GELU(out)), CRL_EPI_F32_RESID (fp32 out = resid + bf16-rounded
- * result). Same arithmetic as crl_gemm_bf16 (fp32 accumulate, bias rounded to bf16); HBM-bound on W. */
+ * result). Same arithmetic as crl_gemm_bf16 (fp32 accumulate, bias rounded to bf16); HBM-bound on W.
+ * out_row_dev (optional, device int): out is advanced by *out_row_dev * out_row_stride elements (the KV-cache row of the
+ * current step, so that the launch is identical for every step of a captured generation graph). */
 int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
                            int64_t ldw, const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
-                           void* stream);
+                           const int* out_row_dev, int64_t out_row_stride, void* stream);
 
 /* column sums of a bf16 matrix into fp32 (bias gradients): out[n] (+)= sum_m X[m,n].
  * ws: >= crl_colsum_ws_bytes(N) bytes of scratch. */
@@ -147,6 +160,9 @@ int crl_vit_tokens_bwd(const float* dx, void* dpatch_bf16, float* dcls, float* d
  * (layernorm_embedding is then crl_layernorm_fwd).  ids int64. */
 int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out,
                   int B, int T, int D, int pos_offset, void* stream);
+/* generation: one token per sequence at position *step_dev (device int) -> f32 [B, D] */
+int crl_embed_decode(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int D, int pos_offset,
+                     const int* step_dev, void* stream);
 /* dtok[ids] += dt (fp32 atomics; dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt. */
 int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos,
                   int B, int T, int D, int pos_offset, void* stream);

@@ -209,12 +209,12 @@ __global__ void colsum_reduce(const float* __restrict__ ws, int N, float* __rest
 // ------------------------------------------------------------------ decoder embedding
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                         const float* __restrict__ pos, float* __restrict__ out,
-                                                        int BT, int T, int D, int off) {
+                                                        int BT, int T, int D, int off, const int* __restrict__ step) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
   const int64_t id = ids[row];
-  const int t = row % T;
+  const int t = row % T + (step ? *step : 0);      // generation: the position comes from the device-side step counter
   const float* tr = tok + (size_t)id * D;
   const float* pr = pos + (size_t)(t + off) * D;
   for (int c = lane * 4; c < D; c += 256) {
@@ -406,8 +406,15 @@ extern "C" int crl_colsum_bf16(const void* X, int64_t M, int64_t N, int64_t ldx,
 extern "C" int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int T, int D,
                              int pos_offset, void* stream) {
   CRL_CHECK(B > 0 && T > 0 && D > 0 && (D % 4) == 0, "crl_embed_fwd: bad shape");
-  embed_fwd_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B * T, T, D, pos_offset);
+  embed_fwd_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B * T, T, D, pos_offset, nullptr);
   CRL_LAUNCH_CHECK("crl_embed_fwd");
+  return 0;
+}
+extern "C" int crl_embed_decode(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int D, int pos_offset,
+                                const int* step_dev, void* stream) {
+  CRL_CHECK(B > 0 && D > 0 && (D % 4) == 0 && step_dev, "crl_embed_decode: bad shape / null step counter");
+  embed_fwd_kernel<<<blocks_for((size_t)B, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B, 1, D, pos_offset, step_dev);
+  CRL_LAUNCH_CHECK("crl_embed_decode");
   return 0;
 }
 extern "C" int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos, int B, int T, int D,

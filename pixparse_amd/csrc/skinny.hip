@@ -14,6 +14,7 @@ struct SkArgs {
   const u16* x; const u16* W; const float* bias; void* out; const float* resid;
   int64_t ldx, ldw, ldo, ldr;
   int M, N, K;
+  const int* out_row; int64_t out_row_stride;   // optional: out += *out_row * out_row_stride (KV-cache row of this step)
 };
 
 template <int EPI>
@@ -48,21 +49,22 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const SkArgs a) {
   }
   const int m = lane & 15, n = n0 + 4 * (lane >> 4);   // this lane: row m, columns n .. n+3
   if (m >= a.M || n >= a.N) return;                     // N % 4 == 0
+  const int64_t row_off = a.out_row ? (int64_t)(*a.out_row) * a.out_row_stride : 0;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
   if (a.bias) {
     const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
     v[0] += round_bf(b.x); v[1] += round_bf(b.y); v[2] += round_bf(b.z); v[3] += round_bf(b.w);
   }
   if constexpr (EPI == CRL_EPI_BF16) {
-    *reinterpret_cast<uint2*>((u16*)a.out + (int64_t)m * a.ldo + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<uint2*>((u16*)a.out + row_off + (int64_t)m * a.ldo + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
   } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
     float y[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[r] = gelu_f(round_bf(v[r]));
-    *reinterpret_cast<uint2*>((u16*)a.out + (int64_t)m * a.ldo + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+    *reinterpret_cast<uint2*>((u16*)a.out + row_off + (int64_t)m * a.ldo + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
   } else {   // CRL_EPI_F32_RESID
     const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)m * a.ldr + n);
-    *reinterpret_cast<float4*>((float*)a.out + (int64_t)m * a.ldo + n) =
+    *reinterpret_cast<float4*>((float*)a.out + row_off + (int64_t)m * a.ldo + n) =
         float4{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
   }
 }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const SkArgs a) {
 
 extern "C" int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
                                       int64_t ldw, const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
-                                      void* stream) {
+                                      const int* out_row_dev, int64_t out_row_stride, void* stream) {
   const char* who = "crl_linear_skinny_bf16";
   CRL_CHECK(x && W && out, "%s: null pointer", who);
   CRL_CHECK(M >= 1 && M <= 16, "%s: M = %d rows (1..16 supported; use crl_gemm_bf16 beyond)", who, M);
@@ -80,7 +82,8 @@ extern "C" int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K,
   CRL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0, "%s: x and W must be 16-byte aligned", who);
   CRL_CHECK(((uintptr_t)out % (epilogue == CRL_EPI_F32_RESID ? 16 : 8)) == 0, "%s: out must be 8-byte (bf16) / 16-byte (fp32) aligned", who);
   CRL_CHECK(N < (1ll << 31) - 16 && K < (1ll << 31) - 32, "%s: extent too large", who);
-  SkArgs a{(const u16*)x, (const u16*)W, bias, out, resid, ldx, ldw, ldo, ldr, M, (int)N, (int)K};
+  CRL_CHECK(!out_row_dev || (out_row_stride % 4) == 0, "%s: out_row_stride must be a multiple of 4 elements", who);
+  SkArgs a{(const u16*)x, (const u16*)W, bias, out, resid, ldx, ldw, ldo, ldr, M, (int)N, (int)K, out_row_dev, out_row_stride};
   const unsigned grid = (unsigned)((N + 15) / 16);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (epilogue == CRL_EPI_BF16) linear_skinny_kernel<CRL_EPI_BF16><<<grid, 256, 0, s>>>(a);

@@ -19,7 +19,9 @@ SIGNATURES = {
     'crl_gemm_ws_bytes': (Z, [I, I, L, L, L]),
     'crl_gemm_set_policy': (I, [I]),
     'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, P, Z, P]),
-    'crl_linear_skinny_bf16': (I, [I, I, L, L, P, L, P, L, P, P, L, P, L, P]),
+    'crl_attn_decode_ws_bytes': (Z, [I, I, I]),
+    'crl_attn_decode': (I, [P, L, P, L, L, P, L, L, P, L, I, I, I, F, P, P, Z, P]),
+    'crl_linear_skinny_bf16': (I, [I, I, L, L, P, L, P, L, P, P, L, P, L, P, L, P]),
     'crl_colsum_ws_bytes': (Z, [L]),
     'crl_colsum_bf16': (I, [P, L, L, L, P, I, P, P]),
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),
@@ -37,6 +39,7 @@ SIGNATURES = {
     'crl_vit_tokens_fwd': (I, [P, P, P, P, I, I, I, P]),
     'crl_vit_tokens_bwd': (I, [P, P, P, P, I, I, I, I, P]),
     'crl_embed_fwd': (I, [P, P, P, P, I, I, I, I, P]),
+    'crl_embed_decode': (I, [P, P, P, P, I, I, I, P, P]),
     'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, P]),
     'crl_cross_entropy': (I, [P, L, P, L, I, F, F, P, P, P, P, P]),
     'crl_grad_norm_ws_bytes': (Z, []),

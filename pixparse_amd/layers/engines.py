@@ -491,10 +491,14 @@ class BartEngine(_Base):
 
     def decode_begin(self, enc16: torch.Tensor, B: int, S: int, max_len: int):
         """enc16 bf16 [B*S, D].  Projects the encoder states to every layer's cross-attention K/V once and lays out
-        empty self-attention K/V caches [B, max_len, 2D] (k | v per row, read by the attention kernel as strided views)."""
+        empty self-attention K/V caches [B, max_len, 2D] (k | v per row, read by the attention kernel as strided views).
+        The step counter lives on the device (`gen.step`): every launch of decode_step has identical arguments, so one
+        captured hipGraph replays the whole step."""
         assert max_len <= self.max_pos, f'max_len {max_len} exceeds the {self.max_pos} learned positions'
         dp, D = self.DP, self.D
-        self.gen = dict(B=B, S=S, max_len=max_len, t=0)
+        step = self.buf('gen.step', (1,), torch.int32)
+        step.zero_()
+        self.gen = dict(B=B, S=S, max_len=max_len, t=0, step=step)
         for i in range(self.L):
             lp = dp + f'layers.{i}.'
             kv2 = self.buf(f'gen.l{i}.kv2', (B * S, 2 * D), BF16)
@@ -502,26 +506,28 @@ class BartEngine(_Base):
             self.buf(f'gen.l{i}.kvc', (B, max_len, 2 * D), BF16)
 
     def decode_step(self, ids: torch.Tensor) -> torch.Tensor:
-        """ids [B, 1] = the token at position t (t = number of tokens fed so far) -> logits bf16 [B, Vp] for position t+1.
-        Same layer arithmetic as forward(); the self-attention sees the cached keys 0..t, nothing is recomputed."""
+        """ids [B, 1] = the token at position step (= number of tokens fed so far) -> logits bf16 [B, Vp] for the next
+        position. Same layer arithmetic as forward(); the self-attention sees the cached keys 0..step, nothing is
+        recomputed. Safe to capture in a hipGraph (no host reads, no allocation after the first call)."""
         g = self.gen
-        B, S, t = g['B'], g['S'], g['t']
-        assert ids.shape == (B, 1) and t < g['max_len']
+        B, S, step = g['B'], g['S'], g['step']
+        assert ids.shape == (B, 1) and g['t'] < g['max_len'], 'KV cache is full'
         dp, D, F_, H = self.DP, self.D, self.F, self.heads
         eps = self.a['ln_eps']
         scale = (D // H) ** -0.5
         emb = self.buf('gen.emb', (B, D), F32)
-        ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2 + t)
+        ops.embed_decode(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, step, 2)
         h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'gen.ln_emb', eps, want_f32=True, want_bf16=True)
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'gen.l{i}'
             kvc = self.bufs.t[self.tag + '.' + k + '.kvc']
             q = self.buf(k + '.q', (B, D), BF16)
             self._lin(hb, self.fw('w', lp, 'self_attn', 'q_proj', 1), self.fb('p', lp, 'self_attn', 'q_proj', 1), q)
-            self._lin(hb, self.fw('w', lp, 'self_attn', 'k_proj', 2), self.fb('p', lp, 'self_attn', 'k_proj', 2), kvc[:, t, :])
+            # k | v of this token straight into cache row `step`
+            ops.linear_skinny(hb, self.fw('w', lp, 'self_attn', 'k_proj', 2), self.fb('p', lp, 'self_attn', 'k_proj', 2), kvc[:, 0, :],
+                              out_row=step, out_row_stride=2 * D)
             o1 = self.buf(k + '.o1', (B, D), BF16)
-            lse = self.buf(k + '.lse', (B, H, 1), F32)
-            ops.attn_fwd(q.view(B, 1, D), kvc[:, :t + 1, 0:D], kvc[:, :t + 1, D:], o1.view(B, 1, D), lse, H, scale, False)
+            ops.attn_decode(q, kvc[:, :, 0:D], kvc[:, :, D:], o1, H, scale, nk_minus1=step)
             t1 = self.buf(k + '.t1', (B, D), F32)
             self._lin(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
             h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
@@ -529,7 +535,7 @@ class BartEngine(_Base):
             self._lin(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
             kv3 = self.bufs.t[self.tag + '.' + k + '.kv2'].view(B, S, 2 * D)
             o2 = self.buf(k + '.o2', (B, D), BF16)
-            ops.attn_fwd(q2.view(B, 1, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, 1, D), lse, H, scale, False)
+            ops.attn_decode(q2, kv3[:, :, 0:D], kv3[:, :, D:], o2, H, scale)
             t2 = self.buf(k + '.t2', (B, D), F32)
             self._lin(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
             h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
@@ -540,7 +546,8 @@ class BartEngine(_Base):
             h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, k + '.ln3', eps, True, True)
         logits = self.buf('gen.logits', (B, self.Vp), BF16)
         self._lin(hb, self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D), None, logits)
-        g['t'] = t + 1
+        step.add_(1)
+        g['t'] += 1
         return logits
 
     def backward(self, dlogits: torch.Tensor, enc16: torch.Tensor, denc: torch.Tensor, on_layer_done=None):

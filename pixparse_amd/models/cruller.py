@@ -268,6 +268,69 @@ class Cruller(nn.Module):
         _, dec, _ = self._ensure_engines()
         return dec.decode_step(input_ids.contiguous())[:, :self.vocab_size]
 
+    def generate_greedy(self, encoder_outputs: torch.Tensor, prompt_id: int, eos_id: int, max_steps: int,
+                        use_graph: bool = True, return_logits: bool = False, check_every: int = 8):
+        """The reference's greedy loop (utils/ocr_utils.py:165-197) on the KV-cache decode path: every sequence starts
+        from prompt_id; iteration r appends arg-max token r unless ALL sequences have produced eos by then (the token of
+        that iteration is not appended). The step has no host-visible state (position, cache row and key count come from
+        a device counter), so after one eager iteration it is captured in a hipGraph and replayed; the host only reads
+        the "all finished at iteration" flag every `check_every` replays. Returns ids [B, n] (and the per-iteration
+        fp32 logits when return_logits, which forces the eager path)."""
+        _, dec, bufs = self._ensure_engines()
+        dev = self.device
+        B = encoder_outputs.shape[0]
+        V = self.vocab_size
+        self.decode_begin(encoder_outputs, max_steps + 1)
+        ids = bufs.get('gen.ids', (B, 1), torch.int64)
+        ids.fill_(prompt_id)
+        tokens = bufs.get('gen.tokens', (B, max_steps + 1), torch.int64)
+        tokens.fill_(prompt_id)
+        finished = bufs.get('gen.finished', (B,), torch.bool)
+        finished.zero_()
+        done_at = bufs.get('gen.done_at', (1,), torch.int32)
+        done_at.fill_(-1)
+        r = bufs.get('gen.r', (1,), torch.int32)
+        r.zero_()
+        steps = []
+
+        def iteration():
+            logits = dec.decode_step(ids)[:, :V]
+            if return_logits:
+                steps.append(logits.float().clone())
+            nxt = torch.argmax(logits, dim=-1, keepdim=True)
+            finished.logical_or_(nxt[:, 0] == eos_id)
+            first = finished.all() & (done_at < 0)
+            done_at.copy_(torch.where(first, r, done_at))
+            tokens.scatter_(1, (r + 1).to(torch.int64).view(1, 1).expand(B, 1), nxt)
+            ids.copy_(nxt)
+            r.add_(1)
+
+        n_done = 0
+        if max_steps > 0:
+            iteration()
+            n_done = 1
+        graph = None
+        if use_graph and not return_logits and max_steps > 1:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration()
+            dec.gen['t'] -= 1       # capture ran the Python body once without executing a step
+        while n_done < max_steps:
+            if int(done_at.item()) >= 0:
+                break
+            for _ in range(min(check_every, max_steps - n_done)):
+                if graph is not None:
+                    graph.replay()
+                    dec.gen['t'] += 1
+                else:
+                    iteration()
+                n_done += 1
+        d = int(done_at.item())
+        n_tokens = 1 + (d if d >= 0 else n_done)
+        out = tokens[:, :n_tokens].clone()
+        return (out, steps[:n_tokens if d < 0 else d + 1]) if return_logits else out
+
     def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0):
         """forward + shifted-token cross-entropy; leaves d(loss*grad_mul)/dlogits in the logits buffer.
         returns the device scalar loss (fp32, = mean NLL * loss_mul)."""

@@ -57,12 +57,14 @@ SKINNY_MAX_ROWS = 16
 
 
 def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16,
-                  resid: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
-    """decode-time linear_fwd for M <= 16 rows (crl_linear_skinny_bf16): every weight byte read once, no tiles"""
+                  resid: Optional[torch.Tensor] = None, n: Optional[int] = None, out_row: Optional[torch.Tensor] = None,
+                  out_row_stride: int = 0) -> None:
+    """decode-time linear_fwd for M <= 16 rows (crl_linear_skinny_bf16): every weight byte read once, no tiles.
+    out_row (device int32 scalar): the output is shifted by out_row * out_row_stride elements (KV-cache row of the step)."""
     M, K = x.shape
     N = n if n is not None else w.shape[0]
     hip.call('crl_linear_skinny_bf16', epi, M, N, K, _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
-             _p(resid), resid.stride(0) if resid is not None else 0, _stream())
+             _p(resid), resid.stride(0) if resid is not None else 0, _p(out_row), int(out_row_stride), _stream())
 
 
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epi: int = EPI_BF16,
@@ -133,6 +135,23 @@ def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool) -> None:
     Nk = k.shape[1]
     hip.call('crl_attn_fwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o), _p(lse),
              B, heads, Nq, Nk, float(scale), int(causal), _stream())
+
+
+def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.Tensor] = None) -> None:
+    """single-query attention over a KV cache: q, o [B, H*64] (row-strided), k / v [B, Nk, H*64] strided views.
+    nk_minus1 (device int32 scalar): only the first nk_minus1 + 1 keys are valid (k.shape[1] is the capacity)."""
+    B = q.shape[0]
+    Nk = k.shape[1]
+    assert q.dim() == 2 and q.stride(1) == 1 and o.stride(1) == 1
+    nbytes = hip.query('crl_attn_decode_ws_bytes', B, heads, Nk)
+    ws = _scratch.get(nbytes, q.device)
+    hip.call('crl_attn_decode', _p(q), q.stride(0), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), o.stride(0), B, heads, Nk,
+             float(scale), _p(nk_minus1), _p(ws), nbytes, _stream())
+
+
+def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) -> None:
+    """generation: ids [B, 1] at position `step` (device int32 scalar) -> out f32 [B, D]"""
+    hip.call('crl_embed_decode', _p(ids), _p(tok), _p(pos), _p(out), ids.shape[0], out.shape[1], pos_offset, _p(step), _stream())
 
 
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool) -> None:

@@ -5,7 +5,8 @@ Same signatures and the same loop semantics as the reference -- every sequence s
 that has produced eos keeps being extended until ALL samples have, the token that completes the last sample is not
 appended -- but where the reference re-runs the whole decoder on the growing prefix for every token, this goes through
 `Cruller.decode_begin` / `decode_step`: cross-attention K/V projected once, self-attention K/V cached, one token of new
-work per step (skinny HBM-bound projections + single-query attention)."""
+work per step (skinny HBM-bound projections + split-KV single-query attention), and the step -- free of host-visible
+state -- is captured once in a hipGraph and replayed (`Cruller.generate_greedy`)."""
 from typing import List, Tuple
 
 import torch
@@ -23,29 +24,12 @@ def get_next_token(next_token_logits: torch.Tensor, use_sample: bool = True, tem
 
 
 def get_generated_tokens(model, tokenizer, encoder_outputs: torch.Tensor, device_env, max_recursion_length: int,
-                         prompt_token: str, return_logits: bool = False):
+                         prompt_token: str, return_logits: bool = False, use_graph: bool = True):
     """ref :165-197. encoder_outputs [B, S, D] from `model.image_encoder(image)`; returns the token ids [B, n] (prompt
     token first). With return_logits also the list of per-step next-token logits (fp32 [B, V]) for parity checks."""
     prompt_id = tokenizer.trunk.encode(prompt_token, add_special_tokens=False)[0]
-    device = device_env.device
-    B = encoder_outputs.shape[0]
-    input_ids = torch.full((B, 1), prompt_id, dtype=torch.int64, device=device)
-    finished = torch.zeros(B, dtype=torch.bool, device=device)
-    eos_token_id = tokenizer.trunk.eos_token_id
-    model.decode_begin(encoder_outputs.to(device), max_recursion_length + 1)
-    steps = []
-    next_input = input_ids
-    for _ in range(max_recursion_length):
-        next_token_logits = model.decode_step(next_input)
-        if return_logits:
-            steps.append(next_token_logits.float().clone())
-        next_token_id, _ = get_next_token(next_token_logits, use_sample=False)
-        finished |= next_token_id.squeeze(-1) == eos_token_id
-        if bool(finished.all()):      # the only host synchronisation of a step, as in the reference
-            break
-        input_ids = torch.cat([input_ids, next_token_id], dim=-1)
-        next_input = next_token_id
-    return (input_ids, steps) if return_logits else input_ids
+    return model.generate_greedy(encoder_outputs.to(device_env.device), prompt_id, tokenizer.trunk.eos_token_id, max_recursion_length,
+                                 use_graph=use_graph, return_logits=return_logits)
 
 
 def generate_ocr(model, tokenizer, encoder_outputs: torch.Tensor, device_env, max_recursion_length: int, prompt_token: str) -> List[str]:

@@ -21,17 +21,18 @@ def main():
     B = a.batch
     image = torch.randn(B, model.in_chans, *model.img_size, device=dev)
     t0 = time.time(); enc = model.image_encoder(image); torch.cuda.synchronize(); t_enc = time.time() - t0
-    t0 = time.time(); model.decode_begin(enc, a.steps + 8); torch.cuda.synchronize(); t_begin = time.time() - t0
-    ids = torch.full((B, 1), 50266, dtype=torch.int64, device=dev)
-    for _ in range(4):                                    # warm-up steps (they also fill cache positions 0..3)
-        ids = model.decode_step(ids).float().argmax(-1, keepdim=True)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.steps):
-        ids = model.decode_step(ids).float().argmax(-1, keepdim=True)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.steps
+    def run(use_graph):
+        torch.cuda.synchronize(); t0 = time.time()
+        out = model.generate_greedy(enc, 50266, -1, a.steps, use_graph=use_graph)      # eos -1: never finishes early
+        torch.cuda.synchronize()
+        return (time.time() - t0) * 1e3, out
+    run(True)                                              # warm-up: allocations, first-touch
+    ms_e, out_e = run(False)
+    ms_g, out_g = run(True)
+    assert torch.equal(out_e, out_g), 'graph replay and eager steps disagree'
+    print(f'eager: {ms_e / a.steps:.3f} ms/step; hipGraph replay: {ms_g / a.steps:.3f} ms/step (includes decode_begin + capture)')
+    ms = ms_g / a.steps
+    t_begin = 0.0
     _, dec, _ = model._engines
     w_bytes = sum(e.numel for n, e in model.arena.entries.items() if n.startswith('text_decoder.') and 'embed_positions' not in n) * 2
     kv_bytes = dec.L * B * dec.gen['S'] * 2 * dec.D * 2

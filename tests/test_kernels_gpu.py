@@ -85,6 +85,11 @@ def test_linear_skinny_vs_gemm_semantics(dev, M, N, K):
     out = torch.empty(M, N, dtype=BF16, device=dev)
     ops.linear_skinny(x, w, None, out)
     close(out, x.float() @ w.float().t(), 1e-2, 1e-2, 'skinny no bias')
+    row = torch.tensor([2], dtype=torch.int32, device=dev)             # device-selected output row (KV-cache write of a graph step)
+    big.zero_()
+    ops.linear_skinny(x, w, bias, big[:, 0, :], out_row=row, out_row_stride=N)
+    close(big[:, 2, :], ref, 1e-2, 1e-2, 'skinny device row')
+    assert float(big[:, :2, :].abs().max()) == 0
     if M <= 16 and N >= 128 and K % 64 == 0:                           # bit-identical to the tiled GEMM? (different summation order: close)
         g = torch.empty(M, N, dtype=BF16, device=dev)
         ops.linear_fwd(x, w, None, g)
@@ -374,6 +379,30 @@ def test_attention_fwd_bwd(dev, B, H, Nq, Nk, causal):
     close(hd(dq, Nq), qf.grad, tol, tol * float(qf.grad.abs().max()), 'dq')
     close(hd(dk, Nk), kf.grad, tol, tol * float(kf.grad.abs().max()), 'dk')
     close(hd(dv, Nk), vf.grad, tol, tol * float(vf.grad.abs().max()), 'dv')
+
+
+@pytest.mark.parametrize('B,H,Nk', [(1, 1, 1), (2, 3, 63), (2, 2, 64), (3, 2, 70), (2, 4, 1000), (1, 16, 6189), (8, 16, 300)])
+def test_attention_decode_single_query(dev, B, H, Nk):
+    """crl_attn_decode (split-KV single-query attention over a strided KV cache) vs the fp32 restatement and vs crl_attn_fwd"""
+    from pixparse_amd import ops
+    D = H * 64
+    q = rnd((B, D), dev, 1.0, 1, BF16)
+    cache = rnd((B, Nk + 5, 2 * D), dev, 1.0, 2, BF16)            # k | v per row, longer than the valid prefix
+    k, v = cache[:, :Nk, :D], cache[:, :Nk, D:]
+    o = torch.zeros(B, D, dtype=BF16, device=dev)
+    ops.attn_decode(q, k, v, o, H, 0.125)
+    hd = lambda t, n: t.float().reshape(B, n, H, 64).transpose(1, 2)
+    oref, _ = attn_ref(hd(q[:, None], 1), hd(k, Nk), hd(v, Nk), 0.125, False)
+    close(hd(o[:, None], 1), oref, 2e-2, 2e-2, 'attn decode')
+    o2 = torch.empty(B, 1, D, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, 1, device=dev)
+    ops.attn_fwd(q[:, None], k, v, o2, lse, H, 0.125, False)
+    close(o, o2[:, 0], 1e-2, 1e-2, 'attn decode vs attn_fwd')
+    # valid prefix taken from a device counter, the view spans the whole cache
+    o3 = torch.zeros_like(o)
+    ops.attn_decode(q, cache[:, :, :D], cache[:, :, D:], o3, H, 0.125, nk_minus1=torch.tensor([Nk - 1], dtype=torch.int32, device=dev))
+    assert torch.equal(o3, o) or Nk + 5 > 256                      # same keys, same split plan -> identical bits (plan differs past one chunk)
+    close(o3, o, 1e-2, 1e-2, 'attn decode, device key count')
 
 
 def test_attention_forced_rescale(dev):

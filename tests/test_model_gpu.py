@@ -329,5 +329,9 @@ def test_greedy_generation_with_kv_cache_vs_oracle(dev, enc, img, fmt, B):
     # same loop semantics as the oracle's restatement of ocr_utils.py:165-197 when it is fed OUR logits' arg-max path
     oids = R.greedy_generate(params, spec, oenc, 514, 2, steps_max, 'bf16')
     assert oids.shape[1] <= steps_max + 1 and oids[:, 0].tolist() == [514] * B
+    # hipGraph replay of the step == eager steps, token for token (same kernels, same arguments)
+    g_ids = get_generated_tokens(model, Tok, enc_out, env, steps_max, '<s_pretrain>', use_graph=True)
+    e_ids = get_generated_tokens(model, Tok, enc_out, env, steps_max, '<s_pretrain>', use_graph=False)
+    assert torch.equal(g_ids, e_ids) and torch.equal(e_ids, ids)
     texts = generate_ocr(model, Tok, enc_out, env, 5, '<s_pretrain>')
     assert len(texts) == B and all(t.startswith('<s_pretrain>') for t in texts)
