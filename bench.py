@@ -10,6 +10,13 @@ A "step" = one TaskCrullerPretrain.train_step(sample) on a synthetic batch of B 
 unscale/clip/AdamW/zero_grad, LR update.  Workload at N=1 = BASELINE.json configs[2]:
 cruller_large (ViT-L/14 CLIP + BART-large 10L) bf16, 1280x960x3, 1024 tokens, batch 8 per GPU.
 Prints ONE JSON line (rank 0) with the driver's contract + `roofline` + `cpu_baseline`.
+
+`roofline` is measured LIVE: libcruller_hip brackets every launch of the attention kernels inside the K timed steps with
+HIP events on the launch stream (crl_prof_begin / crl_prof_end); the kernel symbol with the largest share of the step is
+reported (achieved = sum of algorithmic FLOPs / sum of launch durations, peak = 2.5 PFLOP/s dense bf16). These are the
+launches `rocprofv3 --kernel-trace --stats` averages (profiles/). `roofline.standalone` keeps back-to-back timings of
+single kernels on the live buffers (incl. the fc1 GEMM).  `cpu_baseline` = oracle/ref_cpu.py on the host cores, bounded
+sample, N=1 only.
 """
 import argparse
 import json
@@ -68,6 +75,36 @@ def time_kernel(fn, iters=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+KERNEL_NAMES = ['attn_fwd_kernel<false>', 'attn_fwd_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
+                'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>']
+
+
+def collect_live_profile(steps):
+    """roofline object from the in-library HIP-event timing of the TIMED steps: per kernel symbol the launches, their
+    summed duration and their summed algorithmic FLOPs; the dominant one (largest share of the step) is reported --
+    these are the same launches `rocprofv3 --kernel-trace --stats` averages in profiles/."""
+    import ctypes
+    from pixparse_amd import hip
+    n = len(KERNEL_NAMES)
+    launches = (ctypes.c_int * n)()
+    ms = (ctypes.c_double * n)()
+    work = (ctypes.c_double * n)()
+    hip.call('crl_prof_end', n, ctypes.addressof(launches), ctypes.addressof(ms), ctypes.addressof(work))
+    table = {}
+    for i, name in enumerate(KERNEL_NAMES):
+        if launches[i]:
+            table[name] = {'launches_per_step': round(launches[i] / steps, 1), 'ms_per_launch': round(ms[i] / launches[i], 4),
+                           'ms_per_step': round(ms[i] / steps, 2), 'tflops': round(work[i] / (ms[i] * 1e-3) / 1e12, 1)}
+    if not table:
+        return None
+    i = max(range(n), key=lambda j: ms[j])
+    achieved = work[i] / (ms[i] * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': KERNEL_NAMES[i], 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'ms_per_launch': round(ms[i] / launches[i], 4),
+            'launches_timed': int(launches[i]), 'measured': 'HIP events around every launch inside the timed steps (crl_prof_begin/end)',
+            'kernels': table}
 
 
 def dominant_kernel_roofline(task, B):
@@ -196,11 +233,16 @@ def main():
     for _ in range(args.warmup):
         task.train_step(next(it))
     sync()
+    from pixparse_amd import hip
+    live = env.global_rank == 0 and not args.no_roofline
+    if live:   # HIP events around every attention-kernel launch of the timed steps, on the launch stream (include/crl.h)
+        hip.call('crl_prof_begin', 256 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         task.train_step(next(it))
     sync()
     dt = time.perf_counter() - t0
+    live_prof = collect_live_profile(args.steps) if live else None
     if env.world_size > 1:
         tt = torch.tensor([dt], device=env.device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -227,11 +269,13 @@ def main():
         'activation_gb': round(m.activation_bytes() / 2 ** 30, 2),
     }
     if env.global_rank == 0:
-        if env.world_size == 1 and not args.no_roofline:
-            try:
-                out['roofline'] = dominant_kernel_roofline(task, args.batch)
-            except Exception as e:  # never lose the headline number to the microbench
-                out['roofline'] = {'error': repr(e)}
+        if live_prof is not None:
+            out['roofline'] = live_prof
+            if env.world_size == 1:
+                try:
+                    out['roofline']['standalone'] = dominant_kernel_roofline(task, args.batch)
+                except Exception as e:  # never lose the headline number to the microbench
+                    out['roofline']['standalone'] = {'error': repr(e)}
         if env.world_size == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, f_train)

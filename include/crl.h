@@ -120,6 +120,17 @@ int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
                  void* dv, int64_t dv_bs, int64_t dv_rs,
                  int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
 
+/* Live per-kernel timing for bench.py's roofline object: between crl_prof_begin and crl_prof_end every launch of an
+ * instrumented kernel is bracketed by HIP events on its own stream (pool of `capacity` pairs created up front, no
+ * synchronisation until the end). crl_prof_end fills, per kernel id < n_ids, the number of launches, their summed
+ * duration (ms) and their summed algorithmic work (FLOPs). Kernel ids: */
+#define CRL_K_ATTN_FWD 0        /* attn_fwd_kernel<false>,      + 1 = <true> (causal) */
+#define CRL_K_ATTN_BWD_DKDV 2   /* attn_bwd_dkdv_kernel<false>, + 1 = <true> */
+#define CRL_K_ATTN_BWD_DQ 4     /* attn_bwd_dq_kernel<false>,   + 1 = <true> */
+#define CRL_K_COUNT 6
+int crl_prof_begin(int capacity);
+int crl_prof_end(int n_ids, int* launches, double* ms, double* work);
+
 /* measurement hook (bench.py times the three backward launches one by one): bit0 = delta, bit1 = dK/dV pass,
  * bit2 = dQ pass; default 7 = all. */
 int crl_attn_bwd_set_parts(int parts);

@@ -553,8 +553,12 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
   a.nqt = (Nq + 127) / 128;
   const unsigned grid = (unsigned)a.nqt * B * H;
+  // algorithmic FLOPs: QK^T and PV, 2 x 2 x Nq x Nk x 64 per head (a causal mask halves them when Nq == Nk)
+  const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
+  CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
   if (causal) attn_fwd_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
   else attn_fwd_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a);
+  CRL_PROF_STOP(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream);
   CRL_LAUNCH_CHECK(who);
   return 0;
 }
@@ -593,9 +597,20 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
   }
   const unsigned gk = (unsigned)a.nkt * B * H, gq = (unsigned)a.nqt * B * H;
-  if (g_bwd_parts & 2) { if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a); }
+  // algorithmic backward = dV, dP, dK (dK/dV pass) + dQ (dQ pass): 3 + 1 products of 2 x Nq x Nk x 64 per head; the
+  // recomputed S (both passes) and dP (dQ pass) are executed but not counted
+  const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
+  if (g_bwd_parts & 2) {
+    CRL_PROF_START(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream, 6.0 * 64 * pairs * B * H);
+    if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
+    CRL_PROF_STOP(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream);
+  }
   CRL_LAUNCH_CHECK("crl_attn_bwd(dkdv)");
-  if (g_bwd_parts & 4) { if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a); }
+  if (g_bwd_parts & 4) {
+    CRL_PROF_START(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream, 2.0 * 64 * pairs * B * H);
+    if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
+    CRL_PROF_STOP(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream);
+  }
   CRL_LAUNCH_CHECK("crl_attn_bwd(dq)");
   return 0;
 }

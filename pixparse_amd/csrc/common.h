@@ -117,3 +117,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// live per-kernel timing hooks (capi.cpp); `work` = algorithmic FLOPs (or bytes) of the launch
+extern int g_crl_prof_on;
+extern "C" void crl_prof_mark(int id, int phase, void* stream, double work);
+#define CRL_PROF_START(id, s, work) do { if (g_crl_prof_on) crl_prof_mark((id), 0, (void*)(s), (work)); } while (0)
+#define CRL_PROF_STOP(id, s) do { if (g_crl_prof_on) crl_prof_mark((id), 1, (void*)(s), 0.0); } while (0)

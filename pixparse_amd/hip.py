@@ -31,6 +31,8 @@ SIGNATURES = {
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
                          I, I, I, I, F, I, P]),
     'crl_attn_bwd_set_parts': (I, [I]),
+    'crl_prof_begin': (I, [I]),
+    'crl_prof_end': (I, [I, P, P, P]),
     'crl_swin_attn_fwd': (I, [P, P, P, I, I, I, I, I, I, F, P]),
     'crl_swin_attn_bwd': (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     'crl_patch_merge_fwd': (I, [P, P, I, I, I, I, P]),
