@@ -62,6 +62,9 @@ class ByteBartTokenizer:
         e.input_ids = torch.tensor([ids], dtype=torch.int64)
         return e
 
+    def batch_decode(self, batch, skip_special_tokens=False):
+        return [self.decode(ids, skip_special_tokens) for ids in (batch.tolist() if hasattr(batch, 'tolist') else batch)]
+
     def encode(self, text, add_special_tokens=False):
         return self(text, add_special_tokens=add_special_tokens, max_length=None, padding=False, truncation=False).input_ids[0].tolist()
 

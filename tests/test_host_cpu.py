@@ -432,3 +432,18 @@ def test_finetune_collate_and_token_staging():
     assert seq == '<s_cord><s_menu><s_nm>tea</s_nm><s_cnt>1</s_cnt></s_menu><s_total><s_total_price>3</s_total_price></s_total></s>'
     b = c.collate_fn([{'image': img, 'ground_truth': gt}])
     assert b['label'][0, 0] == c.tokenizer.trunk.convert_tokens_to_ids('<s_cord>') and b['text_target'][0, 0] == c.tokenizer.trunk.convert_tokens_to_ids('<s_menu>')
+
+
+# ------------------------------------------------------------------------------------------- f-4: OCR metrics
+def test_cer_wer_definitions():
+    """jiwer's cer / wer as the reference calls them (utils/ocr_utils.py:32-46, :111-140): batch-summed edit distance over
+    batch-summed reference length; <pad> words removed; WER collapses repeated spaces, CER does not. jiwer itself is not
+    installable here, so these are known answers worked out from its documented definitions (parity unpinned for jiwer)."""
+    from pixparse_amd.utils.ocr_utils import _cer_tokens, _edit_distance, _wer_tokens, get_cer_wer_metrics
+    assert _edit_distance('kitten', 'sitting') == 3 and _edit_distance([], ['a']) == 1 and _edit_distance('abc', 'abc') == 0
+    assert _wer_tokens('  a   b <pad> c<pad> ') == ['a', 'b', 'c<pad>'] and _cer_tokens(' ab <pad> ') == ['a', 'b']
+    m = get_cer_wer_metrics(None, None, {}, ['the cat sat', 'hello  wrld <pad> <pad>'], ['the cat sat on', 'hello world'])
+    assert abs(m['wer'] - 2 / 6) < 1e-12 and abs(m['cer'] - 5 / 25) < 1e-12
+    assert get_cer_wer_metrics(None, None, {}, ['x'], ['']) == {}           # empty reference: jiwer raises, the reference logs and goes on
+    m = get_cer_wer_metrics(None, None, {}, ['same text'], ['same text'])
+    assert m == {'wer': 0.0, 'cer': 0.0}

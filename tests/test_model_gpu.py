@@ -335,3 +335,37 @@ def test_greedy_generation_with_kv_cache_vs_oracle(dev, enc, img, fmt, B):
     assert torch.equal(g_ids, e_ids) and torch.equal(e_ids, ids)
     texts = generate_ocr(model, Tok, enc_out, env, 5, '<s_pretrain>')
     assert len(texts) == B and all(t.startswith('<s_pretrain>') for t in texts)
+
+
+def test_eval_ocr_task_step(dev):
+    """f-4: cruller_eval_ocr through TaskFactory: checkpoint hand-over, step() = encode + KV-cache generation + CER / WER"""
+    from oracle import ref_cpu as R
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.models import Cruller
+    from pixparse_amd.task import TaskCrullerEvalOCR, TaskFactory
+    _register_test_archs()
+    layers, L, img = 2, 24, (37, 50)
+    model_cfg = _cfg('vit_test', img, 'RGB', layers, L)
+    torch.manual_seed(21)
+    trained = Cruller(model_cfg, vocab_size=50267)
+    ckpt = {'module.' + k: v.clone() for k, v in trained.state_dict().items()}
+    task, _ = TaskFactory.create_task('cruller_eval_ocr', dict(model=model_cfg, dtype='bfloat16'), DeviceEnv(), None)
+    assert isinstance(task, TaskCrullerEvalOCR) and task.vocab_size == 50267
+    task.resume_state_dict = ckpt
+    task.setup()
+    k = 'text_decoder.trunk.model.decoder.layers.1.fc2.weight'
+    assert torch.equal(task.model.state_dict()[k].cpu(), ckpt['module.' + k])
+    task.max_recursion_length = 6
+    spec = R.ModelSpec('vit_test', 'bart_test', layers, L, img, 3, vocab=50267)
+    image, tokens, target = R.synthetic_sample(spec, 3, seed=5, ragged=True)
+    tokens = torch.randint(4 + 97, 4 + 122, tokens.shape)                  # printable byte tokens so that the decoded targets are text
+    tokens[:, 0] = 50266
+    tokens[:, 10:] = 1
+    tgt = tokens.clone(); tgt[tgt == 1] = -100; tgt[:, 0] = -100
+    out = task.step((image, [[t] for t in tokens], [[t] for t in tgt]))    # loader format: lists of per-page tensors
+    m = out['ocr_reconstruction']
+    assert m is None or (set(m) <= {'wer', 'cer'} and all(v >= 0 for v in m.values()))
+    if m and 'wer' in m:
+        avg = task.average_metrics({0: out, 1: out})
+        assert avg['ocr_reconstruction'] == {'wer': m['wer'], 'cer': m['cer']}
+    assert set(task.state_dict()) == {'model'}
