@@ -111,7 +111,7 @@ def test_no_cpu_fallback():
     with pytest.raises(ValueError):
         TaskFactory.create_task('nope', {}, DeviceEnv('cpu'), None)
     with pytest.raises(NotImplementedError):
-        TaskFactory.create_task('cruller_eval_ocr', {}, DeviceEnv('cpu'), None)
+        TaskFactory.create_task('cruller_eval_docvqa', {}, DeviceEnv('cpu'), None)   # in the reference's registry, not built here
 
 
 def test_task_surface_and_counters_cpu():
