@@ -57,6 +57,24 @@ def test_argument_validation_without_gpu():
 
 
 # ------------------------------------------------------------------------------------------- model surface
+def test_decode_entry_points_validate_arguments_without_gpu():
+    """the generation kernels refuse bad shapes / null pointers before touching the device"""
+    from pixparse_amd import hip
+    lib = hip.load()
+    assert lib.crl_linear_skinny_bf16(0, 17, 64, 64, 16, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0
+    assert 'M = 17' in hip.last_error()
+    assert lib.crl_linear_skinny_bf16(0, 4, 64, 60, 16, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0      # K % 8
+    assert lib.crl_linear_skinny_bf16(5, 4, 64, 64, 16, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0      # F32_ACC epilogue
+    assert 'epilogue' in hip.last_error()
+    assert lib.crl_linear_skinny_bf16(0, 4, 64, 64, None, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0
+    assert lib.crl_attn_decode(None, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, 16, 1024, None) != 0
+    assert 'null' in hip.last_error()
+    assert lib.crl_attn_decode(16, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, 16, 8, None) != 0       # workspace too small
+    assert 'workspace' in hip.last_error()
+    assert hip.query('crl_attn_decode_ws_bytes', 8, 16, 6189) == 8 * 16 * 7 * 66 * 4      # 128 (b, h) x 7 splits of 1024 keys
+    assert lib.crl_prof_end(6, None, None, None) != 0 and 'not profiling' in hip.last_error()
+
+
 def test_state_dict_keys_match_reference_checkpoint_layout():
     from oracle import ref_cpu as R
     from pixparse_amd.models import Cruller, get_model_config
