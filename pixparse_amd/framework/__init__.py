@@ -5,3 +5,4 @@ from .monitor import Monitor
 from .random import random_seed
 from .task import Task, TaskEval, TaskTrain
 from .train import train_one_interval
+from .eval import evaluate

@@ -369,3 +369,11 @@ def test_eval_ocr_task_step(dev):
         avg = task.average_metrics({0: out, 1: out})
         assert avg['ocr_reconstruction'] == {'wer': m['wer'], 'cer': m['cer']}
     assert set(task.state_dict()) == {'model'}
+    # framework.evaluate: sweeps the accepted loaders, keeps the task's average
+    from pixparse_amd.framework import evaluate
+
+    class _L:
+        loader = [(image, [[t] for t in tokens], [[t] for t in tgt])] * 2
+    if m and 'wer' in m:
+        res = evaluate(task, {'eval': _L, 'train': _L})
+        assert set(res) == {'eval'} and res['eval']['average']['ocr_reconstruction']['wer'] == m['wer']
