@@ -7,6 +7,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
+# torch FIRST: it ships its own libamdhip64; if libcruller_hip.so were dlopen'ed before torch, /opt/rocm's copy would be
+# mapped as well and the process would hold two HIP runtimes -- launches through the second one fail with
+# "no ROCm-capable device is detected" once torch has initialised the GPU (seen with build() followed by smoke()).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libcruller_hip.so')
 

@@ -44,6 +44,15 @@ def test_library_exports_every_declared_symbol():
     assert hip.query('crl_grad_norm_ws_bytes') > 0
 
 
+def test_binding_loads_torch_before_the_hip_library():
+    """regression: dlopen of libcruller_hip.so before torch maps a second HIP runtime (torch ships its own libamdhip64) and
+    every later launch fails with "no ROCm-capable device" -- build() followed by smoke() in one process hit this"""
+    import subprocess, sys
+    code = "import sys; import pixparse_amd.hip as h; assert 'torch' in sys.modules; h.load(); print('ok')"
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-500:]
+
+
 def test_argument_validation_without_gpu():
     """error paths that return before any launch: wrong shapes come back as HipLibraryError with the text"""
     from pixparse_amd import hip
