@@ -2,4 +2,5 @@ from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
 from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
                                     TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 from .task_cruller_eval_ocr import TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg
+from .task_cruller_eval_rvlcdip import TaskCrullerEvalRVLCDIP, TaskCrullerEvalRVLCDIPCfg
 from .task_factory import TaskFactory

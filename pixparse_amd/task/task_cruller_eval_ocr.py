@@ -71,7 +71,8 @@ class TaskCrullerEvalOCR(TaskEval):
         img_std = self.model.image_encoder.trunk.pretrained_cfg['std']
         self.img_mean = sum(img_mean) / len(img_mean) if self.num_image_chs == 1 else img_mean
         self.img_std = sum(img_std) / len(img_std) if self.num_image_chs == 1 else img_std
-        self.image_preprocess_eval = ImagePreprocess(cfg.model.image_encoder.image_size, self.img_mean, self.img_std, self.num_image_chs)
+        self.image_preprocess_eval = ImagePreprocess(cfg.model.image_encoder.image_size, self.img_mean, self.img_std, self.num_image_chs,
+                                                     grayscale=self.num_image_chs == 1)   # RGB pages on an 'L' model are folded to luma
         self.eval_metrics = {}
         self.max_recursion_length = 1000
         self.resume_state_dict = None

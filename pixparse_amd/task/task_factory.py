@@ -4,10 +4,11 @@ clear error."""
 from ..framework import DeviceEnv, Monitor
 from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
 from .task_cruller_eval_ocr import TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg
+from .task_cruller_eval_rvlcdip import TaskCrullerEvalRVLCDIP, TaskCrullerEvalRVLCDIPCfg
 from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
                                     TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 
-_NOT_BUILT = ('cruller_eval_rvlcdip', 'cruller_eval_cord', 'cruller_eval_docvqa', 'donut_eval_ocr',
+_NOT_BUILT = ('cruller_eval_cord', 'cruller_eval_docvqa', 'donut_eval_ocr',
               'cruller_finetune_xent')
 
 
@@ -15,6 +16,7 @@ class TaskFactory:
     TASK_CLASS_REGISTRY = {
         'cruller_pretrain': (TaskCrullerPretrain, TaskCrullerPretrainCfg),
         'cruller_eval_ocr': (TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg),
+        'cruller_eval_rvlcdip': (TaskCrullerEvalRVLCDIP, TaskCrullerEvalRVLCDIPCfg),
         'cruller_finetune_rvlcdip': (TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg),
         'cruller_finetune_cord': (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg),
         'cruller_finetune_docvqa': (TaskCrullerFinetuneDOCVQA, TaskCrullerFinetuneDOCVQACfg),

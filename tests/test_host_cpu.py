@@ -474,3 +474,49 @@ def test_cer_wer_definitions():
     assert get_cer_wer_metrics(None, None, {}, ['x'], ['']) == {}           # empty reference: jiwer raises, the reference logs and goes on
     m = get_cer_wer_metrics(None, None, {}, ['same text'], ['same text'])
     assert m == {'wer': 0.0, 'cer': 0.0}
+
+
+def test_eval_rvlcdip_counting_rule_with_scripted_decoder():
+    """cruller_eval_rvlcdip.step: 5 greedy steps, a sample scores once if at ANY generated </s> the accumulated text is its
+    `<label/>` (ref task_cruller_eval_rvlcdip.py:262-311, incl. the quirk that an early </s> does not end the sample)"""
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    from pixparse_amd.models.archs import register_arch
+    from pixparse_amd.task import TaskCrullerEvalRVLCDIP, TaskFactory
+    register_arch('vit', 'vit_ft_test', dict(patch=8, dim=128, depth=1, heads=2, mlp_ratio=4, ln_eps=1e-6, pre_norm=False, mean=(0.5,) * 3, std=(0.25,) * 3))
+    register_arch('bart', 'bart_ft_test', dict(d_model=128, heads=2, ffn=256, ln_eps=1e-5, vocab=509, dropout=0.0))
+    model = ModelCfg(image_encoder=ImageEncoderCfg(name='vit_ft_test', image_fmt='L', image_size=(32, 40), pretrained=False),
+                     text_decoder=TextDecoderCfg(name='bart_ft_test', pretrained=False, num_decoder_layers=1, max_length=16))
+    task, _ = TaskFactory.create_task('cruller_eval_rvlcdip', dict(model=model, dtype='bfloat16'), DeviceEnv(init_device_type='cpu'), None)
+    assert isinstance(task, TaskCrullerEvalRVLCDIP) and task.vocab_size == 50267 + 19 == task.model.vocab_size
+    ids = task.tokenizer.trunk.convert_tokens_to_ids
+    V = task.vocab_size
+    script = [  # per sample: the 5 tokens the decoder "generates"
+        [ids('<letter/>'), 2, 5, 5, 5],            # label 0 = letter: correct at the first </s>
+        [2, ids('<form/>'), 2, 5, 5],              # label 1 = form: an empty first </s>, right at the second -> counts (quirk)
+        [ids('<memo/>'), 2, 5, 5, 5],              # label 2 = email: wrong class
+        [ids('<email/>'), 9, 2, 5, 5],             # label 2 = email: extra text before </s> -> no
+        [ids('<budget/>'), 2, ids('<budget/>'), 2, 5],   # label 10 = budget: counted once only
+    ]
+
+    class Fake:
+        def __init__(self):
+            self.t = 0
+        def image_encoder(self, x):
+            return torch.zeros(x.shape[0], 3, 128)
+        def decode_begin(self, enc, max_len):
+            self.t = 0
+        def decode_step(self, ids_in):
+            out = torch.full((len(script), V), -1.0)
+            for i, s in enumerate(script):
+                out[i, s[self.t]] = 1.0
+            self.t += 1
+            return out
+    task.model = Fake()
+    sample = {'image': torch.zeros(5, 1, 32, 40), 'label': torch.tensor([0, 1, 2, 2, 10])}
+    m = task.step(sample)
+    assert m == {'classification': {'correct_samples': 3, 'n_valid_samples': 5}}
+    assert task.average_metrics({0: m, 1: m}) == {'classification': {'accuracy': 0.6}}
+    import numpy as np
+    b = task.collate_fn([{'image': np.zeros((50, 60, 3), np.uint8), 'label': 3}, None, {'image': np.zeros((50, 60), np.uint8), 'label': 4}])
+    assert b['image'].shape == (2, 1, 32, 40) and b['label'].tolist() == [3, 4]
