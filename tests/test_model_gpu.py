@@ -377,3 +377,20 @@ def test_eval_ocr_task_step(dev):
     if m and 'wer' in m:
         res = evaluate(task, {'eval': _L, 'train': _L})
         assert set(res) == {'eval'} and res['eval']['average']['ocr_reconstruction']['wer'] == m['wer']
+
+
+def test_eval_rvlcdip_task_step_gpu(dev):
+    """cruller_eval_rvlcdip end to end on the device: 19 class tokens added, 5 KV-cache steps, counts returned"""
+    import numpy as np
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.task import TaskFactory
+    _register_test_archs()
+    model_cfg = _cfg('vit_test', (37, 50), 'L', 2, 16)
+    torch.manual_seed(8)
+    task, _ = TaskFactory.create_task('cruller_eval_rvlcdip', dict(model=model_cfg, dtype='bfloat16'), DeviceEnv(), None)
+    task.setup()
+    rng = np.random.RandomState(1)
+    batch = task.collate_fn([{'image': rng.randint(0, 256, (60, 45)).astype(np.uint8), 'label': int(rng.randint(16))} for _ in range(4)])
+    m = task.step(batch)
+    c = m['classification']
+    assert c['n_valid_samples'] == 4 and 0 <= c['correct_samples'] <= 4
