@@ -63,11 +63,12 @@ int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
  * q [B, H*64] (row stride q_bs), k / v [B, Nk, H*64] strided views (batch stride, row stride in elements), o [B, H*64]
  * bf16. Keys are split over workgroups (HBM-bound); ws >= crl_attn_decode_ws_bytes(B, H, Nk) bytes of scratch.
  * nk_minus1_dev (optional, device int): the valid prefix is *nk_minus1_dev + 1 keys and Nk is the cache capacity -- lets
- * one captured hipGraph serve every step of the generation loop. */
+ * one captured hipGraph serve every step of the generation loop. q_row_dev (optional): q is advanced by *q_row_dev *
+ * q_row_stride elements (the query of the step sits in its cache row). */
 size_t crl_attn_decode_ws_bytes(int B, int H, int Nk);
 int crl_attn_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
                     int64_t v_rs, void* o, int64_t o_bs, int B, int H, int Nk, float scale, const int* nk_minus1_dev,
-                    void* ws, size_t ws_bytes, void* stream);
+                    const int* q_row_dev, int64_t q_row_stride, void* ws, size_t ws_bytes, void* stream);
 
 /* Skinny linear layer for generation (replaces nn.Linear / F.linear on [B, 1, K] decode-step activations inside
  * transformers' BartDecoderLayer, reached from the reference through models/text_decoder_hf.py:39-45 and

@@ -491,7 +491,7 @@ class BartEngine(_Base):
 
     def decode_begin(self, enc16: torch.Tensor, B: int, S: int, max_len: int):
         """enc16 bf16 [B*S, D].  Projects the encoder states to every layer's cross-attention K/V once and lays out
-        empty self-attention K/V caches [B, max_len, 2D] (k | v per row, read by the attention kernel as strided views).
+        empty self-attention caches [B, max_len, 3D] (q | k | v per row, read by the attention kernel as strided views).
         The step counter lives on the device (`gen.step`): every launch of decode_step has identical arguments, so one
         captured hipGraph replays the whole step."""
         assert max_len <= self.max_pos, f'max_len {max_len} exceeds the {self.max_pos} learned positions'
@@ -503,7 +503,7 @@ class BartEngine(_Base):
             lp = dp + f'layers.{i}.'
             kv2 = self.buf(f'gen.l{i}.kv2', (B * S, 2 * D), BF16)
             ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
-            self.buf(f'gen.l{i}.kvc', (B, max_len, 2 * D), BF16)
+            self.buf(f'gen.l{i}.kvc', (B, max_len, 3 * D), BF16)      # q | k | v of every step: one fused projection per token
 
     def decode_step(self, ids: torch.Tensor) -> torch.Tensor:
         """ids [B, 1] = the token at position step (= number of tokens fed so far) -> logits bf16 [B, Vp] for the next
@@ -521,13 +521,12 @@ class BartEngine(_Base):
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'gen.l{i}'
             kvc = self.bufs.t[self.tag + '.' + k + '.kvc']
-            q = self.buf(k + '.q', (B, D), BF16)
-            self._lin(hb, self.fw('w', lp, 'self_attn', 'q_proj', 1), self.fb('p', lp, 'self_attn', 'q_proj', 1), q)
-            # k | v of this token straight into cache row `step`
-            ops.linear_skinny(hb, self.fw('w', lp, 'self_attn', 'k_proj', 2), self.fb('p', lp, 'self_attn', 'k_proj', 2), kvc[:, 0, :],
-                              out_row=step, out_row_stride=2 * D)
+            # q | k | v of this token in ONE projection, straight into cache row `step`; the attention takes q from that row
+            ops.linear_skinny(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), kvc[:, 0, :],
+                              out_row=step, out_row_stride=3 * D)
             o1 = self.buf(k + '.o1', (B, D), BF16)
-            ops.attn_decode(q, kvc[:, :, 0:D], kvc[:, :, D:], o1, H, scale, nk_minus1=step)
+            ops.attn_decode(kvc[:, 0, 0:D], kvc[:, :, D:2 * D], kvc[:, :, 2 * D:], o1, H, scale, nk_minus1=step,
+                            q_row=step, q_row_stride=3 * D)
             t1 = self.buf(k + '.t1', (B, D), F32)
             self._lin(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
             h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)

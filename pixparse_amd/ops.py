@@ -137,16 +137,18 @@ def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool) -> None:
              B, heads, Nq, Nk, float(scale), int(causal), _stream())
 
 
-def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.Tensor] = None) -> None:
+def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.Tensor] = None,
+                q_row: Optional[torch.Tensor] = None, q_row_stride: int = 0) -> None:
     """single-query attention over a KV cache: q, o [B, H*64] (row-strided), k / v [B, Nk, H*64] strided views.
-    nk_minus1 (device int32 scalar): only the first nk_minus1 + 1 keys are valid (k.shape[1] is the capacity)."""
+    nk_minus1 (device int32 scalar): only the first nk_minus1 + 1 keys are valid (k.shape[1] is the capacity);
+    q_row: q is taken q_row * q_row_stride elements further (the step's cache row)."""
     B = q.shape[0]
     Nk = k.shape[1]
     assert q.dim() == 2 and q.stride(1) == 1 and o.stride(1) == 1
     nbytes = hip.query('crl_attn_decode_ws_bytes', B, heads, Nk)
     ws = _scratch.get(nbytes, q.device)
     hip.call('crl_attn_decode', _p(q), q.stride(0), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), o.stride(0), B, heads, Nk,
-             float(scale), _p(nk_minus1), _p(ws), nbytes, _stream())
+             float(scale), _p(nk_minus1), _p(q_row), int(q_row_stride), _p(ws), nbytes, _stream())
 
 
 def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) -> None:

@@ -76,9 +76,9 @@ def test_decode_entry_points_validate_arguments_without_gpu():
     assert lib.crl_linear_skinny_bf16(5, 4, 64, 64, 16, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0      # F32_ACC epilogue
     assert 'epilogue' in hip.last_error()
     assert lib.crl_linear_skinny_bf16(0, 4, 64, 64, None, 64, 16, 64, None, 16, 64, None, 0, None, 0, None) != 0
-    assert lib.crl_attn_decode(None, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, 16, 1024, None) != 0
+    assert lib.crl_attn_decode(None, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, None, 0, 16, 1024, None) != 0
     assert 'null' in hip.last_error()
-    assert lib.crl_attn_decode(16, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, 16, 8, None) != 0       # workspace too small
+    assert lib.crl_attn_decode(16, 64, 16, 64, 64, 16, 64, 64, 16, 64, 1, 1, 8, 0.125, None, None, 0, 16, 8, None) != 0   # workspace too small
     assert 'workspace' in hip.last_error()
     assert hip.query('crl_attn_decode_ws_bytes', 8, 16, 6189) == 8 * 16 * 7 * 66 * 4      # 128 (b, h) x 7 splits of 1024 keys
     assert lib.crl_prof_end(6, None, None, None) != 0 and 'not profiling' in hip.last_error()

@@ -401,8 +401,13 @@ def test_attention_decode_single_query(dev, B, H, Nk):
     # valid prefix taken from a device counter, the view spans the whole cache
     o3 = torch.zeros_like(o)
     ops.attn_decode(q, cache[:, :, :D], cache[:, :, D:], o3, H, 0.125, nk_minus1=torch.tensor([Nk - 1], dtype=torch.int32, device=dev))
-    assert torch.equal(o3, o) or Nk + 5 > 256                      # same keys, same split plan -> identical bits (plan differs past one chunk)
     close(o3, o, 1e-2, 1e-2, 'attn decode, device key count')
+    # query taken from a device-selected row of a [B, rows, 3D] cache
+    qc = torch.zeros(B, 4, 3 * D, dtype=BF16, device=dev)
+    qc[:, 3, :D] = q
+    o4 = torch.zeros_like(o)
+    ops.attn_decode(qc[:, 0, :D], k, v, o4, H, 0.125, q_row=torch.tensor([3], dtype=torch.int32, device=dev), q_row_stride=3 * D)
+    assert torch.equal(o4, o)
 
 
 def test_attention_forced_rescale(dev):
