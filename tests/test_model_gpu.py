@@ -394,3 +394,20 @@ def test_eval_rvlcdip_task_step_gpu(dev):
     m = task.step(batch)
     c = m['classification']
     assert c['n_valid_samples'] == 4 and 0 <= c['correct_samples'] <= 4
+
+
+def test_bench_json_contract(dev, capsys, monkeypatch):
+    """bench.py prints ONE JSON line with the driver's keys + roofline (live) on a small config, in-process"""
+    import importlib, sys as _sys
+    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--model', 'cruller_base_960x640', '--batch', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'])
+    bench = importlib.import_module('bench')
+    bench.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['unit'] == 'docs/s' and d['value'] > 0 and d['scaling'] == 'weak'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and r['kernel'].startswith('attn_') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['launches_timed'] > 0 and r['kernels'][r['kernel']]['ms_per_launch'] == r['ms_per_launch']
