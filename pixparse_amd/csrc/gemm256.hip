@@ -15,6 +15,8 @@
 //   phase 4: (B0 kept in registers)           MFMA Q10      s_waitcnt vmcnt(6): all but the 3 youngest
 //                                                           half-tiles have landed -> next K-tile complete
 // Each phase: {ds_reads, 2 x buffer_load..lds, [vmcnt(6)], s_barrier, MFMA cluster, s_barrier}.
+// Persistent: at most one workgroup per CU (grid = min(tiles, 256) when there is no split-K); after the K loop of a tile
+// the first six half-tiles of the NEXT tile are issued before the epilogue, which only touches registers and global memory.
 // Hazards: RAW -- a buffer is read one phase after the vmcnt+barrier that retires its DMA;
 // WAR -- a half-tile is re-staged at least one full phase (two barriers) after its last ds_read, whose
 // data has been consumed by MFMAs before the closing barrier of that phase.
@@ -38,9 +40,18 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = t / g.ntn, tn = t % g.ntn;
-  const int m0 = tm * 256, n0 = tn * 256;
+#ifndef G_PERSIST
+#define G_PERSIST 1   // one workgroup per CU walks the tile list; the next tile's first K tiles are in flight during the epilogue (same-box A/B: +3..5 % on the K=1024 NT shapes)
+#endif
+  const int ntiles = g.ntm * g.ntn;
+  int logical = blockIdx.x;           // position in the launch order; a persistent workgroup advances it by gridDim.x
+  int m0, n0;
+  auto set_tile = [&](int l) {
+    const int t = xcd_remap(l, ntiles);
+    m0 = (t / g.ntn) * 256;
+    n0 = (t % g.ntn) * 256;
+  };
+  set_tile(logical);
 
   const u32x4 ra = make_srd(g.A, g.a_bytes);
   const u32x4 rb = make_srd(g.B, g.b_bytes);
@@ -52,14 +63,6 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   const int nk = min(nk_all, kt0 + g.kchunk) - kt0;   // K tiles of this split
 
   f32x4 acc[2][2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // LDS-DMA addressing: ONE per-thread byte offset per operand (VGPR) + a wave-uniform part (SGPR soffset) that
   // carries the chunk, the half-tile and the K advance -- keeps the loop free of per-site address registers.
@@ -140,7 +143,18 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   // prologue: half-tiles 0..5 in flight, first K tile (0..3) landed
   issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
   issue(1, 0); issue(1, 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  bool first_tile = true;
+  for (;;) {   // output tiles of this workgroup (exactly one unless G_PERSIST)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetched half-tiles AND the previous epilogue's stores
   BAR();
   // stagger (guide §5 template): the wr==1 waves run one barrier behind, so on every SIMD one wave is in its
   // MFMA cluster while its partner (the wave 4 slots away shares the SIMD) issues LDS reads and DMA.
@@ -196,6 +210,13 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   // ~80 VGPRs across the loop and push the accumulators into scratch)
   int lane_e = lane, m0e = m0, n0e = n0;
   asm volatile("" : "+v"(lane_e), "+s"(m0e), "+s"(n0e));
+  const int next_logical = logical + (int)gridDim.x;
+  const bool has_next = G_PERSIST && gridDim.y == 1 && next_logical < ntiles;
+  if (has_next) {   // LDS is idle from here on: stage the next tile's first six half-tiles under the epilogue
+    set_tile(next_logical);
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+    issue(1, 0); issue(1, 1);
+  }
   const int li = lane_e & 15, lq = lane_e >> 4;
 #pragma unroll
   for (int qm = 0; qm < 2; ++qm)
@@ -245,6 +266,10 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
           }
         }
     }
+  if (!has_next) break;
+  logical = next_logical;
+  first_tile = false;
+  }
 }
 
 template <int LAYOUT, int EPI>
@@ -256,7 +281,11 @@ int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
     if (e != hipSuccess) { crl_set_error("gemm256: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -2; }
     configured = true;
   }
-  gemm256_kernel<LAYOUT, EPI><<<dim3(a.ntm * a.ntn, nsplit), T256, 131072, s>>>(a);
+  int grid_x = a.ntm * a.ntn;
+#if G_PERSIST
+  if (nsplit == 1 && grid_x > 256) grid_x = 256;   // one resident workgroup per CU walks the tiles
+#endif
+  gemm256_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T256, 131072, s>>>(a);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(256)");
   return 0;
 }
