@@ -41,7 +41,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   const int wr = wave >> 2, wc = wave & 3;
 
 #ifndef G_PERSIST
-#define G_PERSIST 1   // one workgroup per CU walks the tile list; the next tile's first K tiles are in flight during the epilogue (same-box A/B: +3..5 % on the K=1024 NT shapes)
+#define G_PERSIST 1   // one workgroup per CU walks the tile list; the next tile's first K tiles are in flight during the epilogue (same-box A/B: +3..5 % on the K=1024 NT shapes, +0.1 % on the whole cfg-3 step)
 #endif
   const int ntiles = g.ntm * g.ntn;
   int logical = blockIdx.x;           // position in the launch order; a persistent workgroup advances it by gridDim.x
