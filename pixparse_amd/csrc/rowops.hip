@@ -181,11 +181,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
   const int c0 = blockIdx.x * 256 + cg * 8;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < N) {
-    for (int r = blockIdx.y * 8 + rl; r < M; r += CS_SPLIT * 8) {
-      const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)r * ldx + c0);
+    auto add = [&](const uint4 v) {
       a[0] += bf2f(v.x & 0xffff); a[1] += bf2f(v.x >> 16); a[2] += bf2f(v.y & 0xffff); a[3] += bf2f(v.y >> 16);
       a[4] += bf2f(v.z & 0xffff); a[5] += bf2f(v.z >> 16); a[6] += bf2f(v.w & 0xffff); a[7] += bf2f(v.w >> 16);
+    };
+    constexpr int S = CS_SPLIT * 8;
+    const u16* p = X + c0;
+    int r = blockIdx.y * 8 + rl;
+    for (; r + 3 * S < M; r += 4 * S) {   // four independent 16-B loads in flight per thread (one per iteration left the kernel latency-bound)
+      const uint4 v0 = *reinterpret_cast<const uint4*>(p + (size_t)r * ldx);
+      const uint4 v1 = *reinterpret_cast<const uint4*>(p + (size_t)(r + S) * ldx);
+      const uint4 v2 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 2 * S) * ldx);
+      const uint4 v3 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 3 * S) * ldx);
+      add(v0); add(v1); add(v2); add(v3);
     }
+    for (; r < M; r += S) add(*reinterpret_cast<const uint4*>(p + (size_t)r * ldx));
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = a[j];
