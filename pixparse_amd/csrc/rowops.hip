@@ -87,19 +87,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int row = blockIdx.x * 4 + wave; row < M; row += nw) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     const size_t ro = (size_t)row * D;
+    // All loads of a row are issued kind by kind BEFORE the arithmetic (fp32 dy, bf16 dy, x; gamma stays cached): the
+    // wave then waits for one round trip per kind instead of one per 1-KB slot (the per-slot form measured 160 us for
+    // 49512 x 1024 -- latency-bound at 2 waves per SIMD although it looked like 5 TB/s).
     float4 gv[LN_MAXV], xh[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) gv[i] = float4{0, 0, 0, 0};
+    if (dy32) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) gv[i] = *reinterpret_cast<const float4*>(dy32 + ro + c);
+      }
+    }
+    uint2 hb[LN_MAXV];
+    if (dy16) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        hb[i] = uint2{0u, 0u};
+        if (c < D) hb[i] = *reinterpret_cast<const uint2*>(dy16 + ro + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      xh[i] = float4{mean, mean, mean, mean};
+      if (c < D) xh[i] = *reinterpret_cast<const float4*>(x + ro + c);
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
-        float4 d{0, 0, 0, 0};
-        if (dy32) d = *reinterpret_cast<const float4*>(dy32 + ro + c);
+        float4 d = gv[i];
         if (dy16) {
-          const uint2 h = *reinterpret_cast<const uint2*>(dy16 + ro + c);
+          const uint2 h = hb[i];
           d.x += bf2f(h.x & 0xffff); d.y += bf2f(h.x >> 16); d.z += bf2f(h.y & 0xffff); d.w += bf2f(h.y >> 16);
         }
-        const float4 xv = *reinterpret_cast<const float4*>(x + ro + c);
+        const float4 xv = xh[i];
         const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
         float4 h{(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
         ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
@@ -111,6 +137,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       }
     }
     const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    float4 old[LN_MAXV];
+    if (dx32 && dx_acc) {   // the accumulated residual gradient: one batch of loads, not a read-modify-write per slot
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        old[i] = float4{0, 0, 0, 0};
+        if (c < D) old[i] = *reinterpret_cast<const float4*>(dx32 + ro + c);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -118,9 +153,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float4 o{rstd * (gv[i].x - c1 - xh[i].x * c2), rstd * (gv[i].y - c1 - xh[i].y * c2),
                  rstd * (gv[i].z - c1 - xh[i].z * c2), rstd * (gv[i].w - c1 - xh[i].w * c2)};
         if (dx32) {
-          float4* p = reinterpret_cast<float4*>(dx32 + ro + c);
-          if (dx_acc) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-          *p = o;
+          if (dx_acc) { o.x += old[i].x; o.y += old[i].y; o.z += old[i].z; o.w += old[i].w; }
+          *reinterpret_cast<float4*>(dx32 + ro + c) = o;
         }
         if (dx16) *reinterpret_cast<uint2*>(dx16 + ro + c) = uint2{pack_bf2(o.x, o.y), pack_bf2(o.z, o.w)};
       }
