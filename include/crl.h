@@ -171,13 +171,15 @@ int crl_vit_tokens_bwd(const float* dx, void* dpatch_bf16, float* dcls, float* d
  * hf:609,648-651: t = embed_tokens[ids] * 1.0 + embed_positions[arange(T) + 2]  -> f32 [B*T, D].
  * (layernorm_embedding is then crl_layernorm_fwd).  ids int64. */
 int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out,
-                  int B, int T, int D, int pos_offset, void* stream);
+                  int B, int T, int D, int pos_offset, int vocab, void* stream);
 /* generation: one token per sequence at position *step_dev (device int) -> f32 [B, D] */
 int crl_embed_decode(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int D, int pos_offset,
-                     const int* step_dev, void* stream);
-/* dtok[ids] += dt (fp32 atomics; dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt. */
+                     int vocab, const int* step_dev, void* stream);
+/* dtok[ids] += dt (fp32 atomics: the order of the adds to a row that occurs several times is not fixed, so this
+ * gradient is reproducible only to fp32 rounding; dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt.
+ * ids outside [0, vocab) (torch: device assert): forward rows become NaN, backward skips them -- never out of bounds. */
 int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos,
-                  int B, int T, int D, int pos_offset, void* stream);
+                  int B, int T, int D, int pos_offset, int vocab, void* stream);
 
 /* ---------------------------------------------------------------- shifted-token cross-entropy
  * ref: task/task_cruller_pretrain.py:118,251-256  nn.CrossEntropyLoss(ignore_index=-100) on bf16
@@ -185,10 +187,12 @@ int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos,
  * logits [M, ldl] bf16 (only the first V columns are read).  On return
  *   loss[0] = mean NLL * loss_mul  (fp32), n_valid[0] = number of non-ignored rows (int32),
  *   dlogits (may alias logits) = bf16((softmax - onehot) * grad_mul / n_valid), columns V..ldl-1 zeroed.
+ * grad_mul_dev (optional, device): one more factor on the gradient read on the device -- the GradScaler loss scale
+ *   that crl_grad_norm_scaled keeps in state[4].  A target outside [0, V) other than -100 makes the loss NaN.
  * row_loss: scratch [M] fp32. */
 int crl_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, int64_t M, int V,
-                      float loss_mul, float grad_mul, float* loss, int32_t* n_valid, float* row_loss,
-                      void* dlogits, void* stream);
+                      float loss_mul, float grad_mul, const float* grad_mul_dev, float* loss, int32_t* n_valid,
+                      float* row_loss, void* dlogits, void* stream);
 
 /* ---------------------------------------------------------------- optimiser over the flat arenas
  * ref: task/task_cruller_pretrain.py:191-206,259-295 -> timm NativeScaler (GradScaler unscale,
@@ -196,12 +200,22 @@ int crl_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, in
  * optimizer.zero_grad().
  * crl_grad_norm: state[0] = ||g||_2 * inv_scale, state[1] = clip coefficient
  *   min(1, max_norm / (norm + 1e-6)) * inv_scale (or inv_scale when max_norm <= 0),
- *   state[2] = 1.0 if any grad is inf/nan else 0.0.   ws >= crl_grad_norm_ws_bytes(). */
+ *   state[2] = 1.0 if any grad is inf/nan else 0.0, state[3] += 1 when the step will be taken (torch's
+ *   state['step'] does not advance on a step GradScaler skips).   ws >= crl_grad_norm_ws_bytes(); state: >= 4 floats.
+ * crl_grad_norm_scaled: the same with torch.amp.GradScaler kept on the device (state: 8 floats): the loss scale is
+ *   state[4], inv_scale = 1 / (state[4] * grad_divisor) (grad_divisor = data-parallel world size: the all-reduce sums),
+ *   and after the inf check  state[4] *= backoff_factor, state[5] = 0  on inf/nan, else  state[5] += 1 and every
+ *   growth_interval clean steps  state[4] *= growth_factor  (torch _amp_update_scale_): no host synchronisation,
+ *   the next crl_cross_entropy reads the updated scale through grad_mul_dev = &state[4]. */
 size_t crl_grad_norm_ws_bytes(void);
 int crl_grad_norm(const float* g, int64_t n, float max_norm, float inv_scale, float* state, void* ws,
                   void* stream);
+int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, float grad_divisor, float growth_factor,
+                         float backoff_factor, int growth_interval, float* state, void* ws, void* stream);
 /* p,m,v updated in place with g*state[1]; skipped entirely when state[2] != 0 (GradScaler.step);
- * p_bf16 (optional) receives the bf16 shadow of the new p; g is zeroed when zero_grad != 0. */
+ * p_bf16 (optional) receives the bf16 shadow of the new p; g is zeroed when zero_grad != 0.
+ * step >= 1: bias corrections 1 - beta^step from the host's count; step == 0: from state[3], the device-side count of
+ * steps actually taken (advanced by crl_grad_norm* only when the step is not skipped). */
 int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int step, const float* state, int zero_grad,
               void* stream);

@@ -530,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 
 int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) {
   CRL_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "%s: empty problem", who);
-  CRL_CHECK(rs_min >= 64, "%s: row stride must be >= 64 elements", who);
+  CRL_CHECK(rs_min >= (int64_t)H * 64, "%s: head_dim is 64 (head h at channel 64 h): a row must hold H * 64 = %d channels, row stride is %lld",
+            who, H * 64, (long long)rs_min);
   return 0;
 }
 #define CHK_STRIDE(name, p, bs, rs)                                                                         \
@@ -543,7 +544,11 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
                             const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
                             float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream) {
   const char* who = "crl_attn_fwd";
-  if (check_common(who, B, H, Nq, Nk, q_rs < k_rs ? (q_rs < v_rs ? q_rs : v_rs) : (k_rs < v_rs ? k_rs : v_rs))) return -1;
+  {
+    int64_t rs_min = q_rs;
+    for (int64_t r : {k_rs, v_rs, o_rs}) rs_min = r < rs_min ? r : rs_min;
+    if (check_common(who, B, H, Nq, Nk, rs_min)) return -1;
+  }
   CRL_CHECK(q && k && v && o && lse, "%s: null pointer", who);
   CHK_STRIDE("q", q, q_bs, q_rs); CHK_STRIDE("k", k, k_bs, k_rs); CHK_STRIDE("v", v, v_bs, v_rs); CHK_STRIDE("o", o, o_bs, o_rs);
   CHK_EXTENT("k", Nk, k_rs); CHK_EXTENT("v", Nk, v_rs);
@@ -578,7 +583,11 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
                             void* dv, int64_t dv_bs, int64_t dv_rs, int B, int H, int Nq, int Nk, float scale, int causal,
                             void* stream) {
   const char* who = "crl_attn_bwd";
-  if (check_common(who, B, H, Nq, Nk, 64)) return -1;
+  {
+    int64_t rs_min = q_rs;
+    for (int64_t r : {k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs}) rs_min = r < rs_min ? r : rs_min;
+    if (check_common(who, B, H, Nq, Nk, rs_min)) return -1;
+  }
   CRL_CHECK(q && k && v && o && d_o && lse && delta && dq && dk && dv, "%s: null pointer", who);
   CHK_STRIDE("q", q, q_bs, q_rs); CHK_STRIDE("k", k, k_bs, k_rs); CHK_STRIDE("v", v, v_bs, v_rs); CHK_STRIDE("o", o, o_bs, o_rs);
   CHK_STRIDE("do", d_o, do_bs, do_rs); CHK_STRIDE("dq", dq, dq_bs, dq_rs); CHK_STRIDE("dk", dk, dk_bs, dk_rs); CHK_STRIDE("dv", dv, dv_bs, dv_rs);

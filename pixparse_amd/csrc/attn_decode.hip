@@ -164,7 +164,7 @@ extern "C" int crl_attn_decode(const void* q, int64_t q_bs, const void* k, int64
   CRL_CHECK(!q_row_dev || (q_row_stride % 8) == 0, "%s: q_row_stride must be a multiple of 8 elements", who);
   CRL_CHECK(B > 0 && H > 0 && Nk > 0, "%s: empty problem", who);
   CRL_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && (q_bs % 8) == 0 && (k_bs % 8) == 0 &&
-                (k_rs % 8) == 0 && (v_bs % 8) == 0 && (v_rs % 8) == 0 && k_rs >= 64 && v_rs >= 64,
+                (k_rs % 8) == 0 && (v_bs % 8) == 0 && (v_rs % 8) == 0 && k_rs >= (int64_t)H * 64 && v_rs >= (int64_t)H * 64,
             "%s: operands must be 16-byte aligned with strides multiple of 8 elements", who);
   DecArgs a{};
   a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.o = (u16*)o; a.ws = (float*)ws;

@@ -31,14 +31,15 @@ __device__ __forceinline__ float block_reduce_max(float v, float* sh) {
 __global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* __restrict__ target, int M, int32_t* __restrict__ n_valid) {
   __shared__ float sh[4];
   float c = 0.f;
-  for (int i = threadIdx.x; i < M; i += 256) c += (target[i] != -100) ? 1.f : 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) c += (target[i] != -100) ? 1.f : 0.f;   // like torch: every non-ignored row counts
   const float t = block_reduce_sum(c, sh);
   if (threadIdx.x == 0) *n_valid = (int32_t)(t + 0.5f);
 }
 
 // one workgroup per row: pass 1 online (max, sum exp) over the bf16 logits, pass 2 writes the gradient
 __global__ __launch_bounds__(256) void ce_row_kernel(const u16* __restrict__ logits, int ldl, const int64_t* __restrict__ target,
-                                                     int V, float grad_mul, const int32_t* __restrict__ n_valid,
+                                                     int V, float grad_mul, const float* __restrict__ grad_mul_dev,
+                                                     const int32_t* __restrict__ n_valid,
                                                      float* __restrict__ row_loss, u16* __restrict__ dlogits) {
   __shared__ float sh[4];
   const int row = blockIdx.x;
@@ -46,8 +47,11 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const u16* __restrict__ log
   const u16* lr = logits + (size_t)row * ldl;
   u16* dr = dlogits + (size_t)row * ldl;
   const int nch = ldl / 8;
-  if (tgt == -100) {
-    if (threadIdx.x == 0) row_loss[row] = 0.f;
+  // a target outside [0, V) that is not the ignore index is a caller bug (torch raises a device assert): the row's loss
+  // becomes NaN -- the step's loss and the optimiser's inf/nan check both show it -- and nothing is read out of bounds
+  const bool invalid = tgt != -100 && (tgt < 0 || tgt >= V);
+  if (tgt == -100 || invalid) {
+    if (threadIdx.x == 0) row_loss[row] = invalid ? __builtin_nanf("") : 0.f;
     for (int ch = threadIdx.x; ch < nch; ch += 256) *reinterpret_cast<uint4*>(dr + ch * 8) = uint4{0, 0, 0, 0};
     return;
   }
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const u16* __restrict__ log
   const float gsm = block_reduce_sum(sm, sh);
   const float lse = gmx + __logf(gsm);
   if (threadIdx.x == 0) row_loss[row] = lse - tgt_logit;
-  const float gm = grad_mul / (float)(*n_valid);
+  const float gm = grad_mul * (grad_mul_dev ? *grad_mul_dev : 1.f) / (float)(*n_valid);
   for (int ch = threadIdx.x; ch < nch; ch += 256) {
     const uint4 v = *reinterpret_cast<const uint4*>(lr + ch * 8);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -114,31 +118,49 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   const float t = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, float max_norm, float inv_scale,
-                                                              float* __restrict__ state) {
+// SCALED: the loss scale lives in state[4] (GradScaler on the device): inv_scale = 1 / (state[4] * grad_divisor), and after
+// the inf check the scale / growth tracker are updated exactly like torch's _amp_update_scale_ -- the next step's
+// cross-entropy reads the new scale from the same word, so an overflow costs exactly one skipped step and no host sync.
+template <bool SCALED>
+__global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, float max_norm, float inv_scale_or_div,
+                                                              float growth, float backoff, float interval, float* __restrict__ state) {
   __shared__ float sh[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < GN_BLOCKS; i += 256) s += partial[i];
   const float t = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) {
     const bool bad = !(t == t) || t == INFINITY;
+    const float inv_scale = SCALED ? 1.f / (state[4] * inv_scale_or_div) : inv_scale_or_div;
     const float norm = sqrtf(t) * inv_scale;
     float coef = inv_scale;
     if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (norm + 1e-6f));
     state[0] = norm;
     state[1] = bad ? 0.f : coef;
     state[2] = bad ? 1.f : 0.f;
+    if (!bad) state[3] += 1.f;          // optimiser steps actually taken (torch: state['step'] is not advanced on a skipped step)
+    if (SCALED) {
+      if (bad) { state[4] *= backoff; state[5] = 0.f; }
+      else {
+        state[5] += 1.f;
+        if (state[5] >= interval) { state[4] *= growth; state[5] = 0.f; }
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, u16* __restrict__ pb, size_t n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float rsqrt_bc2,
-                                                    const float* __restrict__ state, int zero_grad) {
+                                                    const float* __restrict__ state, int zero_grad, int dev_step) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const float coef = state ? state[1] : 1.f;
   const bool skip = state ? (state[2] != 0.f) : false;
+  if (dev_step && !skip) {               // bias corrections from the device-side count of steps taken (this one included)
+    const float t = state[3];
+    bc1 = 1.f - __builtin_amdgcn_exp2f(t * __builtin_amdgcn_logf(b1));
+    rsqrt_bc2 = __builtin_amdgcn_rsqf(1.f - __builtin_amdgcn_exp2f(t * __builtin_amdgcn_logf(b2)));
+  }
   if (i + 3 < n) {
     float4 pv = *reinterpret_cast<float4*>(p + i);
     if (!skip) {
@@ -178,13 +200,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 }  // namespace
 
 extern "C" int crl_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, int64_t M, int V, float loss_mul,
-                                 float grad_mul, float* loss, int32_t* n_valid, float* row_loss, void* dlogits, void* stream) {
+                                 float grad_mul, const float* grad_mul_dev, float* loss, int32_t* n_valid, float* row_loss,
+                                 void* dlogits, void* stream) {
   CRL_CHECK(M > 0 && V > 0 && ldl >= V && (ldl % 8) == 0, "crl_cross_entropy: bad shape M=%lld V=%d ldl=%lld", (long long)M, V, (long long)ldl);
   CRL_CHECK(logits && target && loss && n_valid && row_loss && dlogits, "crl_cross_entropy: null pointer");
   hipStream_t s = as_stream(stream);
   ce_count_kernel<<<1, 256, 0, s>>>(target, (int)M, n_valid);
   CRL_LAUNCH_CHECK("crl_cross_entropy(count)");
-  ce_row_kernel<<<(unsigned)M, 256, 0, s>>>((const u16*)logits, (int)ldl, target, V, grad_mul, n_valid, row_loss, (u16*)dlogits);
+  ce_row_kernel<<<(unsigned)M, 256, 0, s>>>((const u16*)logits, (int)ldl, target, V, grad_mul, grad_mul_dev, n_valid, row_loss, (u16*)dlogits);
   CRL_LAUNCH_CHECK("crl_cross_entropy(rows)");
   ce_finish_kernel<<<1, 256, 0, s>>>(row_loss, (int)M, n_valid, loss_mul, loss);
   CRL_LAUNCH_CHECK("crl_cross_entropy(finish)");
@@ -199,19 +222,35 @@ extern "C" int crl_grad_norm(const float* g, int64_t n, float max_norm, float in
   hipStream_t s = as_stream(stream);
   sumsq_kernel<<<GN_BLOCKS, 256, 0, s>>>(g, (size_t)n, (float*)ws);
   CRL_LAUNCH_CHECK("crl_grad_norm(sumsq)");
-  gradnorm_finish_kernel<<<1, 256, 0, s>>>((const float*)ws, max_norm, inv_scale, state);
+  gradnorm_finish_kernel<false><<<1, 256, 0, s>>>((const float*)ws, max_norm, inv_scale, 0.f, 0.f, 0.f, state);
   CRL_LAUNCH_CHECK("crl_grad_norm(finish)");
+  return 0;
+}
+
+extern "C" int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, float grad_divisor, float growth_factor,
+                                    float backoff_factor, int growth_interval, float* state, void* ws, void* stream) {
+  CRL_CHECK(n > 0 && g && state && ws, "crl_grad_norm_scaled: bad args");
+  CRL_CHECK(((uintptr_t)g % 16) == 0, "crl_grad_norm_scaled: grad arena must be 16-byte aligned");
+  CRL_CHECK(grad_divisor > 0.f && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0,
+            "crl_grad_norm_scaled: bad scaler parameters");
+  hipStream_t s = as_stream(stream);
+  sumsq_kernel<<<GN_BLOCKS, 256, 0, s>>>(g, (size_t)n, (float*)ws);
+  CRL_LAUNCH_CHECK("crl_grad_norm_scaled(sumsq)");
+  gradnorm_finish_kernel<true><<<1, 256, 0, s>>>((const float*)ws, max_norm, grad_divisor, growth_factor, backoff_factor,
+                                                 (float)growth_interval, state);
+  CRL_LAUNCH_CHECK("crl_grad_norm_scaled(finish)");
   return 0;
 }
 
 extern "C" int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, const float* state, int zero_grad, void* stream) {
-  CRL_CHECK(n > 0 && p && g && m && v && step >= 1, "crl_adamw: bad args");
+  CRL_CHECK(n > 0 && p && g && m && v && (step >= 1 || (step == 0 && state)), "crl_adamw: bad args (step >= 1, or step == 0 with the device-side counter in state[3])");
   CRL_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0, "crl_adamw: arenas must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int hs = step >= 1 ? step : 1;
+  const double bc1 = 1.0 - pow((double)beta1, hs), bc2 = 1.0 - pow((double)beta2, hs);
   const unsigned blocks = (unsigned)(((size_t)n + 1023) / 1024);
   adamw_kernel<<<blocks, 256, 0, as_stream(stream)>>>(p, g, m, v, (u16*)p_bf16, (size_t)n, lr, beta1, beta2, eps, weight_decay,
-                                                      (float)bc1, (float)(1.0 / sqrt(bc2)), state, zero_grad);
+                                                      (float)bc1, (float)(1.0 / sqrt(bc2)), state, zero_grad, step == 0 ? 1 : 0);
   CRL_LAUNCH_CHECK("crl_adamw");
   return 0;
 }

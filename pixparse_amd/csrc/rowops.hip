@@ -253,12 +253,17 @@ __global__ void colsum_reduce(const float* __restrict__ ws, int N, float* __rest
 // ------------------------------------------------------------------ decoder embedding
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                         const float* __restrict__ pos, float* __restrict__ out,
-                                                        int BT, int T, int D, int off, const int* __restrict__ step) {
+                                                        int BT, int T, int D, int off, const int* __restrict__ step, int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
   const int64_t id = ids[row];
   const int t = row % T + (step ? *step : 0);      // generation: the position comes from the device-side step counter
+  if (id < 0 || id >= vocab) {                     // torch raises a device assert: here the row turns NaN (visible in the loss), nothing is read
+    const float nanv = __builtin_nanf("");
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4*>(out + (size_t)row * D + c) = float4{nanv, nanv, nanv, nanv};
+    return;
+  }
   const float* tr = tok + (size_t)id * D;
   const float* pr = pos + (size_t)(t + off) * D;
   for (int c = lane * 4; c < D; c += 256) {
@@ -268,11 +273,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dt,
-                                                            float* __restrict__ dtok, int BT, int D) {
+                                                            float* __restrict__ dtok, int BT, int D, int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
-  float* dr = dtok + (size_t)ids[row] * D;
+  const int64_t id = ids[row];
+  if (id < 0 || id >= vocab) return;   // never scatter outside the embedding entry (its neighbours in the arena are other parameters' gradients)
+  float* dr = dtok + (size_t)id * D;
   for (int c = lane; c < D; c += 64) atomicAdd(dr + c, dt[(size_t)row * D + c]);  // 256 contiguous bytes per wave-instruction
 }
 __global__ void embed_bwd_pos_kernel(const float* __restrict__ dt, float* __restrict__ dpos, int acc, int B, int T, int D, int off) {
@@ -448,24 +455,24 @@ extern "C" int crl_colsum_bf16(const void* X, int64_t M, int64_t N, int64_t ldx,
 }
 
 extern "C" int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int T, int D,
-                             int pos_offset, void* stream) {
-  CRL_CHECK(B > 0 && T > 0 && D > 0 && (D % 4) == 0, "crl_embed_fwd: bad shape");
-  embed_fwd_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B * T, T, D, pos_offset, nullptr);
+                             int pos_offset, int vocab, void* stream) {
+  CRL_CHECK(B > 0 && T > 0 && D > 0 && (D % 4) == 0 && vocab > 0, "crl_embed_fwd: bad shape");
+  embed_fwd_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B * T, T, D, pos_offset, nullptr, vocab);
   CRL_LAUNCH_CHECK("crl_embed_fwd");
   return 0;
 }
 extern "C" int crl_embed_decode(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int D, int pos_offset,
-                                const int* step_dev, void* stream) {
-  CRL_CHECK(B > 0 && D > 0 && (D % 4) == 0 && step_dev, "crl_embed_decode: bad shape / null step counter");
-  embed_fwd_kernel<<<blocks_for((size_t)B, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B, 1, D, pos_offset, step_dev);
+                                int vocab, const int* step_dev, void* stream) {
+  CRL_CHECK(B > 0 && D > 0 && (D % 4) == 0 && vocab > 0 && step_dev, "crl_embed_decode: bad shape / null step counter");
+  embed_fwd_kernel<<<blocks_for((size_t)B, 4), 256, 0, as_stream(stream)>>>(ids, tok, pos, out, B, 1, D, pos_offset, step_dev, vocab);
   CRL_LAUNCH_CHECK("crl_embed_decode");
   return 0;
 }
 extern "C" int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos, int B, int T, int D,
-                             int pos_offset, void* stream) {
-  CRL_CHECK(B > 0 && T > 0 && D > 0, "crl_embed_bwd: bad shape");
+                             int pos_offset, int vocab, void* stream) {
+  CRL_CHECK(B > 0 && T > 0 && D > 0 && vocab > 0, "crl_embed_bwd: bad shape");
   hipStream_t s = as_stream(stream);
-  embed_bwd_tok_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, s>>>(ids, dt, dtok, B * T, D);
+  embed_bwd_tok_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, s>>>(ids, dt, dtok, B * T, D, vocab);
   CRL_LAUNCH_CHECK("crl_embed_bwd(tok)");
   embed_bwd_pos_kernel<<<blocks_for((size_t)T * D, 256), 256, 0, s>>>(dt, dpos, acc_pos, B, T, D, pos_offset);
   CRL_LAUNCH_CHECK("crl_embed_bwd(pos)");

@@ -22,6 +22,13 @@ def is_distributed_env():
     return False
 
 
+def launched_by_torchrun():
+    """torchrun / torch.distributed.run exports all of these, also for a single rank: such a process takes the distributed
+    branch (RCCL communicator, bucketed reducer) even when WORLD_SIZE == 1, so `bench.py --gpus 1` under the launcher
+    walks exactly the code `--gpus 8` does."""
+    return all(v in os.environ for v in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'))
+
+
 def world_info_from_env():
     local_rank = 0
     for v in ('LOCAL_RANK', 'MPI_LOCALRANKID', 'SLURM_LOCALID', 'OMPI_COMM_WORLD_LOCAL_RANK'):
@@ -58,6 +65,7 @@ class DeviceEnv:
     world_size: Optional[int] = None
     local_rank: Optional[int] = None
     global_rank: Optional[int] = None
+    distributed: bool = False   # a process group exists (world_size > 1, or a single rank started by torchrun)
 
     def is_global_primary(self):
         return self.global_rank == 0
@@ -75,7 +83,7 @@ class DeviceEnv:
         if use_cuda:
             assert torch.cuda.device_count(), 'no HIP device visible'
         init_local_rank, init_global_rank, init_world_size = world_info_from_env()
-        if init_world_size > 1:
+        if init_world_size > 1 or launched_by_torchrun():
             assert init_device_index is None
             self.local_rank = int(init_local_rank)
             backend = init_dist_backend if use_cuda else 'gloo'
@@ -95,6 +103,7 @@ class DeviceEnv:
                     dist.init_process_group(backend=backend, init_method=init_dist_url)
             self.world_size = dist.get_world_size()
             self.global_rank = dist.get_rank()
+            self.distributed = True
             self.device = torch.device('cuda:%d' % device_index) if use_cuda else torch.device('cpu')
         else:
             if use_cuda:

@@ -2,9 +2,10 @@
 259-295 -> timm create_optimizer_v2('adamw') = torch.optim.AdamW(weight_decay=0), timm NativeScaler =
 torch GradScaler, dispatch_clip_grad('norm') = clip_grad_norm_, timm CosineLRScheduler).
 
-Everything device-side runs in two launches over contiguous memory: crl_grad_norm (sum of squares ->
-norm, inf check, clip coefficient, all left in device memory) and crl_adamw (unscale * clip, AdamW,
-zero_grad and the bf16 shadow refresh fused).  No host synchronisation anywhere in a step.
+Everything device-side runs in two launches over contiguous memory: crl_grad_norm_scaled (sum of squares ->
+norm, inf check, clip coefficient, GradScaler.update(), step counter: all left in device memory) and crl_adamw
+(unscale * clip, AdamW with bias corrections from the device-side step count, zero_grad and the bf16 shadow refresh
+fused).  No host synchronisation anywhere in a step.
 """
 import math
 from typing import Optional
@@ -14,37 +15,58 @@ import torch
 from .. import ops
 
 
+STATE_FLOATS = 8   # [0] grad norm, [1] clip * unscale coefficient, [2] found inf/nan, [3] optimiser steps TAKEN,
+                   # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6..7] unused   (include/crl.h)
+
+
 class ArenaAdamW:
-    """torch.optim.AdamW semantics (single param group, decoupled weight decay) on a ParamArena."""
+    """torch.optim.AdamW semantics (single param group, decoupled weight decay) on a ParamArena.  The step counter that
+    feeds the bias corrections lives on the device (state[3]) and advances only when the step is taken: a step that
+    GradScaler skips (inf / nan gradients) leaves it unchanged, exactly like torch's `state['step']`."""
 
     def __init__(self, arena, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         self.arena = arena
         self.param_groups = [dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
-        self.step_count = 0
         arena.alloc_training_state()
-        self.state = torch.zeros(4, dtype=torch.float32, device=arena.p.device)  # [norm, coef, found_inf, -]
+        self.state = torch.zeros(STATE_FLOATS, dtype=torch.float32, device=arena.p.device)
+        self.state[4] = 1.0   # no loss scaling until a LossScaler attaches
+
+    @property
+    def step_count(self) -> int:
+        """optimiser steps actually taken (reads the device counter: a host sync, for checkpoints / tests only)"""
+        return int(round(float(self.state[3])))
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.g.zero_()
 
-    def step(self, clip_norm: Optional[float] = None, inv_scale: float = 1.0, zero_grad: bool = False):
+    def step(self, clip_norm: Optional[float] = None, inv_scale: Optional[float] = None, zero_grad: bool = False,
+             scaler: Optional['LossScaler'] = None, grad_divisor: float = 1.0):
+        """unscale / inf check / clip-norm coefficient, then AdamW (skipped on inf / nan).  With `scaler` the loss scale is
+        the device word state[4] and GradScaler.update() happens inside the same launch (crl_grad_norm_scaled);
+        without it `inv_scale` is a host number (plain crl_grad_norm)."""
         g = self.param_groups[0]
         a = self.arena
-        ops.grad_norm(a.g, clip_norm if clip_norm is not None else 0.0, inv_scale, self.state)
-        self.step_count += 1
-        ops.adamw(a.p, a.g, a.m, a.v, a.pb, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
-                  self.step_count, self.state, zero_grad)
+        mx = clip_norm if clip_norm is not None else 0.0
+        if scaler is not None and scaler.enabled:
+            ops.grad_norm_scaled(a.g, mx, grad_divisor, scaler.growth_factor, scaler.backoff_factor, scaler.growth_interval, self.state)
+        else:
+            ops.grad_norm(a.g, mx, (1.0 if inv_scale is None else inv_scale) / (grad_divisor if inv_scale is None else 1.0), self.state)
+        ops.adamw(a.p, a.g, a.m, a.v, a.pb, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0, self.state, zero_grad)
 
     def grad_norm(self) -> torch.Tensor:
         """device scalar: unscaled global L2 norm seen by the last step()"""
         return self.state[0]
+
+    def found_inf(self) -> torch.Tensor:
+        """device scalar: 1.0 when the last step() saw inf / nan gradients and was skipped"""
+        return self.state[2]
 
     def state_dict(self):
         return dict(step=self.step_count, param_groups=[dict(g) for g in self.param_groups],
                     exp_avg=self.arena.m.clone(), exp_avg_sq=self.arena.v.clone())
 
     def load_state_dict(self, sd):
-        self.step_count = sd['step']
+        self.state[3] = float(sd['step'])
         self.param_groups = [dict(g) for g in sd['param_groups']]
         self.arena.m.copy_(sd['exp_avg'])
         self.arena.v.copy_(sd['exp_avg_sq'])
@@ -81,49 +103,44 @@ class CosineLRScheduler:
 
 
 class LossScaler:
-    """torch.amp.GradScaler bookkeeping (init 65536, x2 every 2000 clean steps, x0.5 on inf/nan) without host
-    syncs: the found-inf flag of step t is copied to pinned memory asynchronously and folded into the scale
-    when it has arrived (normally before step t+1).  With bf16 the scale is a power of two and cancels exactly."""
+    """torch.amp.GradScaler (init 65536, x2 every 2000 clean steps, x0.5 on inf / nan) with the scale and the growth
+    tracker resident on the DEVICE (words 4 and 5 of the optimiser's state vector): the cross-entropy kernel multiplies
+    the gradient by the scale it reads there, crl_grad_norm_scaled unscales with the same word, decides found-inf and
+    applies GradScaler.update() -- the step after an overflow already runs with the halved scale, with no host
+    synchronisation anywhere.  With bf16 the scale is a power of two and cancels exactly."""
 
     def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
-        self.scale = float(init_scale) if enabled else 1.0
-        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._init_scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self.enabled = enabled
-        self._growth_tracker = 0
-        self._pending = []  # (event, pinned tensor)
+        self._state = None         # the optimiser's device state vector once attached
+        self._host = [self._init_scale, 0.0]
 
-    def get_scale(self):
-        return self.scale
+    def attach(self, state: torch.Tensor):
+        """bind to the optimiser's state vector (>= 8 floats); the current scale / tracker move there"""
+        assert state.numel() >= 8
+        state[4] = self._host[0]
+        state[5] = self._host[1]
+        self._state = state
+        return self
 
-    def note_step(self, state: torch.Tensor):
-        if not self.enabled or not state.is_cuda:
-            return
-        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-        host.copy_(state[2:3], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pending.append((ev, host))
+    def scale_tensor(self) -> Optional[torch.Tensor]:
+        """device fp32 scalar holding the loss scale (None while detached or disabled)"""
+        return self._state[4:5] if (self._state is not None and self.enabled) else None
 
-    def update(self):
-        still = []
-        for ev, host in self._pending:
-            if ev.query():
-                if float(host[0]) != 0.0:
-                    self.scale *= self.backoff_factor
-                    self._growth_tracker = 0
-                else:
-                    self._growth_tracker += 1
-                    if self._growth_tracker == self.growth_interval:
-                        self.scale *= self.growth_factor
-                        self._growth_tracker = 0
-            else:
-                still.append((ev, host))
-        self._pending = still
+    def get_scale(self) -> float:
+        """host copy of the scale (synchronises when attached: logging / checkpoints only)"""
+        return float(self._state[4]) if self._state is not None else self._host[0]
+
+    def get_growth_tracker(self) -> int:
+        return int(round(float(self._state[5]))) if self._state is not None else int(self._host[1])
 
     def state_dict(self):
-        return dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
-                    growth_interval=self.growth_interval, _growth_tracker=self._growth_tracker)
+        return dict(scale=self.get_scale(), growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
+                    growth_interval=self.growth_interval, _growth_tracker=self.get_growth_tracker())
 
     def load_state_dict(self, sd):
-        self.scale = sd['scale']
-        self._growth_tracker = sd.get('_growth_tracker', 0)
+        self._host = [float(sd['scale']), float(sd.get('_growth_tracker', 0))]
+        if self._state is not None:
+            self._state[4] = self._host[0]
+            self._state[5] = self._host[1]

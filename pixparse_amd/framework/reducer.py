@@ -18,8 +18,13 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, arena, world_size: int, bucket_bytes: int = 64 << 20, group=None):
-        self.arena, self.world_size, self.group = arena, world_size, group
+    def __init__(self, arena, world_size: int, bucket_bytes: int = 64 << 20, group=None, active: Optional[bool] = None,
+                 op=dist.ReduceOp.SUM):
+        """active: run the collectives (default: world_size > 1). A single rank started by torchrun passes True so that
+        the N = 1 run exercises the same RCCL calls as N = 8. `op` is SUM in production (tests pass a pre-multiplied
+        sum to make the collective observable on one rank)."""
+        self.arena, self.world_size, self.group, self.op = arena, world_size, group, op
+        self.active = (world_size > 1) if active is None else bool(active)
         n = max(1, bucket_bytes // 4)
         total = arena.total
         self.buckets: List[Tuple[int, int]] = []
@@ -34,7 +39,7 @@ class BucketedGradReducer:
 
     def broadcast_params(self, src: int = 0):
         """DDP constructor semantics (C1): every rank starts from rank 0's parameters."""
-        if self.world_size > 1:
+        if self.active:
             dist.broadcast(self.arena.p, src=src, group=self.group)
 
     def begin(self):
@@ -42,12 +47,12 @@ class BucketedGradReducer:
         self._works = []
 
     def _fire_until(self, offset: int):
-        if not self.enabled or self.world_size == 1:
+        if not self.enabled or not self.active:
             return
         g = self.arena.g
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
             s, e = self.buckets[self._next]
-            self._works.append(dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(g[s:e], op=self.op, group=self.group, async_op=True))
             self._next += 1
 
     def on_ready(self, name: str):

@@ -45,12 +45,13 @@ SIGNATURES = {
     'crl_im2row': (I, [P, P, I, I, I, I, I, I, I, I, P]),
     'crl_vit_tokens_fwd': (I, [P, P, P, P, I, I, I, P]),
     'crl_vit_tokens_bwd': (I, [P, P, P, P, I, I, I, I, P]),
-    'crl_embed_fwd': (I, [P, P, P, P, I, I, I, I, P]),
-    'crl_embed_decode': (I, [P, P, P, P, I, I, I, P, P]),
-    'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, P]),
-    'crl_cross_entropy': (I, [P, L, P, L, I, F, F, P, P, P, P, P]),
+    'crl_embed_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
+    'crl_embed_decode': (I, [P, P, P, P, I, I, I, I, P, P]),
+    'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    'crl_cross_entropy': (I, [P, L, P, L, I, F, F, P, P, P, P, P, P]),
     'crl_grad_norm_ws_bytes': (Z, []),
     'crl_grad_norm': (I, [P, L, F, F, P, P, P]),
+    'crl_grad_norm_scaled': (I, [P, L, F, F, F, F, I, P, P, P]),
     'crl_adamw': (I, [P, P, P, P, P, L, F, F, F, F, F, I, P, I, P]),
     'crl_cast_bf16': (I, [P, P, L, P]),
     'crl_cast_pad_bf16': (I, [P, P, L, L, L, P]),

@@ -98,6 +98,8 @@ class ViTEngine(_Base):
         self.N = self.Np + 1
         self.D = arch['dim']
         self.heads = arch['heads']
+        if self.D != self.heads * ops.HEAD_DIM:
+            raise ValueError(f"ViT arch dim {self.D} / heads {self.heads}: the attention kernels are built for head_dim {ops.HEAD_DIM}")
         self.F = self.D * arch['mlp_ratio']
         self.Kreal = in_chans * self.P_ * self.P_
         self.Kp = ops.round_up(self.Kreal, ops.K_PAD)
@@ -400,6 +402,8 @@ class BartEngine(_Base):
         self.a, self.L, self.V, self.max_pos = arch, n_layers, vocab, max_pos
         self.Vp = ops.round_up(vocab, ops.VOCAB_PAD)
         self.D, self.heads, self.F = arch['d_model'], arch['heads'], arch['ffn']
+        if self.D != self.heads * ops.HEAD_DIM:
+            raise ValueError(f"BART arch d_model {self.D} / heads {self.heads}: the attention kernels are built for head_dim {ops.HEAD_DIM}")
 
     @staticmethod
     def param_shapes(arch, n_layers, vocab, max_pos):

@@ -48,6 +48,7 @@ class ImageEncoderCfg(_Serializable):
     image_fmt: str = 'L'
     image_size: Optional[Tuple[int, int]] = (576, 448)
     pretrained: bool = True
+    pretrained_path: Optional[str] = None   # local timm state dict (file or directory); see models/pretrained.py
 
 
 @dataclass
@@ -57,6 +58,7 @@ class TextDecoderCfg(_Serializable):
     num_decoder_layers: Optional[int] = 4
     max_length: Optional[int] = 1024
     pad_token_id: Optional[int] = None
+    pretrained_path: Optional[str] = None   # local HF BART state dict (file or directory); see models/pretrained.py
 
 
 @dataclass

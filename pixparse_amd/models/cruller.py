@@ -123,6 +123,10 @@ class Cruller(nn.Module):
         self._engines = None
         self._build()
         self.reset_parameters()
+        # pretrained=True (the reference default, image_encoder_timm.py:13-20 / text_decoder_hf.py:25-31): local weights when
+        # they can be found, otherwise a loud warning -- never a silent random init
+        from .pretrained import load_pretrained
+        self.pretrained_sources = load_pretrained(self)
 
     # ------------------------------------------------------------------ structure
     def _enc_shapes(self):
@@ -331,7 +335,8 @@ class Cruller(nn.Module):
         out = tokens[:, :n_tokens].clone()
         return (out, steps[:n_tokens if d < 0 else d + 1]) if return_logits else out
 
-    def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0):
+    def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0,
+                     grad_mul_dev: Optional[torch.Tensor] = None):
         """forward + shifted-token cross-entropy; leaves d(loss*grad_mul)/dlogits in the logits buffer.
         returns the device scalar loss (fp32, = mean NLL * loss_mul)."""
         enc, dec, bufs = self._ensure_engines()
@@ -343,7 +348,7 @@ class Cruller(nn.Module):
         n_valid = bufs.get('n_valid', (1,), torch.int32)
         row_loss = bufs.get('row_loss', (M,), torch.float32)
         self._target = text_target.contiguous().view(-1)
-        ops.cross_entropy(logits, self._target, self.vocab_size, loss_mul, grad_mul, self._loss, n_valid, row_loss, logits)
+        ops.cross_entropy(logits, self._target, self.vocab_size, loss_mul, grad_mul, self._loss, n_valid, row_loss, logits, grad_mul_dev)
         return self._loss
 
     def backward(self, on_ready: Optional[Callable[[str], None]] = None):

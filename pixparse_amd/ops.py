@@ -123,6 +123,16 @@ def layernorm_bwd(dy_f32, dy_bf16, x, gamma, mean, rstd, dx_f32, dx_accumulate, 
              int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), int(acc_wgrad), _p(ws), _stream())
 
 
+HEAD_DIM = 64   # the attention kernels index head h at channel h * 64
+
+
+def _chk_heads(heads: int, *tensors) -> None:
+    for t in tensors:
+        if t.shape[-1] != heads * HEAD_DIM:
+            raise ValueError(f'attention kernels are built for head_dim {HEAD_DIM}: got {t.shape[-1]} channels for {heads} heads '
+                             f'(head_dim {t.shape[-1] / max(heads, 1):g})')
+
+
 def _bs_rs(t: torch.Tensor):
     """(batch stride, row stride) in elements of a [B, N, H*64-ish] view whose last dim is contiguous."""
     assert t.dim() == 3 and t.stride(2) == 1, 'attention operands are [B, N, H*64] views with contiguous channels'
@@ -133,6 +143,7 @@ def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool) -> None:
     """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32."""
     B, Nq, _ = q.shape
     Nk = k.shape[1]
+    _chk_heads(heads, q, k, v, o)
     hip.call('crl_attn_fwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o), _p(lse),
              B, heads, Nq, Nk, float(scale), int(causal), _stream())
 
@@ -145,6 +156,7 @@ def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.
     B = q.shape[0]
     Nk = k.shape[1]
     assert q.dim() == 2 and q.stride(1) == 1 and o.stride(1) == 1
+    _chk_heads(heads, q, k, v, o)
     nbytes = hip.query('crl_attn_decode_ws_bytes', B, heads, Nk)
     ws = _scratch.get(nbytes, q.device)
     hip.call('crl_attn_decode', _p(q), q.stride(0), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), o.stride(0), B, heads, Nk,
@@ -153,12 +165,14 @@ def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.
 
 def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) -> None:
     """generation: ids [B, 1] at position `step` (device int32 scalar) -> out f32 [B, D]"""
-    hip.call('crl_embed_decode', _p(ids), _p(tok), _p(pos), _p(out), ids.shape[0], out.shape[1], pos_offset, _p(step), _stream())
+    hip.call('crl_embed_decode', _p(ids), _p(tok), _p(pos), _p(out), ids.shape[0], out.shape[1], pos_offset, tok.shape[0], _p(step),
+             _stream())
 
 
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool) -> None:
     B, Nq, _ = q.shape
     Nk = k.shape[1]
+    _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)
     hip.call('crl_attn_bwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o),
              _p(d_o), *_bs_rs(d_o), _p(lse), _p(delta), _p(dq), *_bs_rs(dq), _p(dk), *_bs_rs(dk), _p(dv), *_bs_rs(dv),
              B, heads, Nq, Nk, float(scale), int(causal), _stream())
@@ -197,17 +211,19 @@ def vit_tokens_bwd(dx, dpatch, dcls, dpos, B, Np, D, accumulate: bool = True) ->
 
 def embed_fwd(ids, tok, pos, out, pos_offset: int = 2) -> None:
     B, T = ids.shape
-    hip.call('crl_embed_fwd', _p(ids), _p(tok), _p(pos), _p(out), B, T, out.shape[1], pos_offset, _stream())
+    hip.call('crl_embed_fwd', _p(ids), _p(tok), _p(pos), _p(out), B, T, out.shape[1], pos_offset, tok.shape[0], _stream())
 
 
 def embed_bwd(ids, dt, dtok, dpos, pos_offset: int = 2, accumulate: bool = True) -> None:
     B, T = ids.shape
-    hip.call('crl_embed_bwd', _p(ids), _p(dt), _p(dtok), _p(dpos), int(accumulate), B, T, dt.shape[1], pos_offset, _stream())
+    hip.call('crl_embed_bwd', _p(ids), _p(dt), _p(dtok), _p(dpos), int(accumulate), B, T, dt.shape[1], pos_offset, dtok.shape[0], _stream())
 
 
-def cross_entropy(logits, target, V: int, loss_mul: float, grad_mul: float, loss, n_valid, row_loss, dlogits) -> None:
+def cross_entropy(logits, target, V: int, loss_mul: float, grad_mul: float, loss, n_valid, row_loss, dlogits,
+                  grad_mul_dev: Optional[torch.Tensor] = None) -> None:
+    """grad_mul_dev: device fp32 scalar multiplied into the gradient on the device (the GradScaler loss scale)"""
     M = logits.shape[0]
-    hip.call('crl_cross_entropy', _p(logits), logits.stride(0), _p(target), M, V, float(loss_mul), float(grad_mul),
+    hip.call('crl_cross_entropy', _p(logits), logits.stride(0), _p(target), M, V, float(loss_mul), float(grad_mul), _p(grad_mul_dev),
              _p(loss), _p(n_valid), _p(row_loss), _p(dlogits), _stream())
 
 
@@ -216,7 +232,17 @@ def grad_norm(g, max_norm: float, inv_scale: float, state) -> None:
     hip.call('crl_grad_norm', _p(g), g.numel(), float(max_norm), float(inv_scale), _p(state), _p(ws), _stream())
 
 
+def grad_norm_scaled(g, max_norm: float, grad_divisor: float, growth_factor: float, backoff_factor: float, growth_interval: int,
+                     state) -> None:
+    """unscale + inf check + clip coefficient + GradScaler.update() on the device (state: 8 floats, scale in state[4])"""
+    assert state.numel() >= 8
+    ws = _scratch.get(hip.query('crl_grad_norm_ws_bytes'), g.device)
+    hip.call('crl_grad_norm_scaled', _p(g), g.numel(), float(max_norm), float(grad_divisor), float(growth_factor), float(backoff_factor),
+             int(growth_interval), _p(state), _p(ws), _stream())
+
+
 def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step: int, state, zero_grad: bool) -> None:
+    """step >= 1: host-side step number; step == 0: the device-side count of steps taken in state[3]"""
     hip.call('crl_adamw', _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
              float(eps), float(weight_decay), int(step), _p(state), int(zero_grad), _stream())
 

@@ -125,12 +125,13 @@ class TaskCrullerPretrain(TaskTrain):
         # NOTE weight_decay is not forwarded, exactly like the reference (:196-203) -> 0
         self.optimizer = ArenaAdamW(self.model.arena, lr=opt.learning_rate, eps=opt.eps, weight_decay=0.0, **kw)
         self.model._ensure_engines()
-        self.reducer = BucketedGradReducer(self.model.arena, self.device_env.world_size)
-        if self.device_env.world_size > 1:
+        self.reducer = BucketedGradReducer(self.model.arena, self.device_env.world_size,
+                                           active=getattr(self.device_env, 'distributed', self.device_env.world_size > 1))
+        if self.reducer.active:
             self.reducer.broadcast_params(0)
             self.model.refresh_shadows(full=True)
             self.has_no_sync = True
-        self.scaler = LossScaler(enabled=True)
+        self.scaler = LossScaler(enabled=True).attach(self.optimizer.state)
         self.autocast = None
         self.num_steps_per_interval = num_batches_per_interval // opt.grad_accum_steps
         self.scheduler = CosineLRScheduler(self.optimizer, t_initial=self.num_intervals * self.num_steps_per_interval,
@@ -152,21 +153,19 @@ class TaskCrullerPretrain(TaskTrain):
         """autocast(bf16){ model -> logits -> CE(ignore_index=-100) } / grad_accum_steps  (ref :247-257).
         inputs already on device and shifted; returns the device scalar loss and leaves dloss/dlogits ready."""
         accum = self.cfg.opt.grad_accum_steps
-        return self.model.forward_loss(image_input, text_input, text_target, loss_mul=1.0 / accum,
-                                       grad_mul=self.scaler.get_scale() / accum)
+        return self.model.forward_loss(image_input, text_input, text_target, loss_mul=1.0 / accum, grad_mul=1.0 / accum,
+                                       grad_mul_dev=self.scaler.scale_tensor())
 
     def _backward(self, need_update: bool):
         self.reducer.enabled = need_update or not self.has_no_sync
         self.reducer.begin()
-        self.model.backward(self.reducer.on_ready if self.device_env.world_size > 1 else None)
+        self.model.backward(self.reducer.on_ready if self.reducer.active else None)
         self.reducer.finish()
         if need_update:
             opt = self.cfg.opt
-            inv_scale = 1.0 / (self.scaler.get_scale() * self.reducer.grad_divisor())
-            self.optimizer.step(clip_norm=opt.clip_grad_value, inv_scale=inv_scale, zero_grad=True)
+            # NativeScaler.__call__ (ref :259-278): unscale_ -> clip_grad_norm_ -> scaler.step (skips on inf/nan) -> scaler.update
+            self.optimizer.step(clip_norm=opt.clip_grad_value, zero_grad=True, scaler=self.scaler, grad_divisor=self.reducer.grad_divisor())
             self.model.refresh_shadows(full=False)
-            self.scaler.note_step(self.optimizer.state)
-            self.scaler.update()
 
     log_phase_name = 'train'
 

@@ -1,8 +1,19 @@
 """Tokenizer config + wrapper (ref: tokenizers/config.py:14-17, tokenizers/tokenizer_hf.py:6-18).
-`facebook/bart-large` cannot be fetched offline, so when the HF files are not in the local cache a
-byte-level stand-in with BART's special ids (bos 0, pad 1, eos 2, vocab 50265) is used; it only feeds
-synthetic benches and tests -- real-data tokenisation is the f-1 'next' row of SURVEY §8."""
+
+`TokenizerHF(cfg)` = `transformers.AutoTokenizer.from_pretrained(cfg.name)` like the reference.  This image has no
+network and no cached `facebook/bart-large` files, so a byte-level stand-in with BART's special ids (bos 0, pad 1, eos 2,
+vocab 50265) exists for synthetic benches and tests.  It is never substituted silently:
+  * `TokenizerCfg(name='byte-bart')` selects it explicitly (bench.py and the tests do);
+  * any other name is loaded through transformers (local cache first, then the hub unless HF_HUB_OFFLINE is set);
+    if that fails the error is logged at WARNING level with the reason and the stand-in is used -- its vocabulary is
+    INCOMPATIBLE with real BART checkpoints -- unless PIXPARSE_AMD_STRICT_TOKENIZER=1, which re-raises."""
+import logging
+import os
+import warnings
 from dataclasses import dataclass
+
+_logger = logging.getLogger(__name__)
+BYTE_TOKENIZER = 'byte-bart'
 
 
 @dataclass
@@ -84,11 +95,29 @@ class ByteBartTokenizer:
         return s + out.decode('utf-8', 'replace')
 
 
+class TokenizerFallbackWarning(UserWarning):
+    pass
+
+
 class TokenizerHF:
     def __init__(self, cfg: TokenizerCfg):
         self.trunk = None
+        if cfg.name == BYTE_TOKENIZER:
+            self.trunk = ByteBartTokenizer()
+            return
         try:
             import transformers
-            self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name, local_files_only=True)
-        except Exception:
+            try:
+                self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name, local_files_only=True)
+            except Exception:
+                if os.environ.get('HF_HUB_OFFLINE', '0') == '1':
+                    raise
+                self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name)
+        except Exception as e:  # noqa: BLE001  (import error, cache miss, no network, typo in the name ...)
+            if os.environ.get('PIXPARSE_AMD_STRICT_TOKENIZER', '0') == '1':
+                raise
+            msg = (f'tokenizer {cfg.name!r} could not be loaded ({type(e).__name__}: {str(e)[:200]}); using the byte-level stand-in '
+                   f'({BYTE_TOKENIZER}): its vocabulary is NOT compatible with real BART checkpoints or real-data runs')
+            warnings.warn(msg, TokenizerFallbackWarning, stacklevel=2)
+            _logger.warning(msg)
             self.trunk = ByteBartTokenizer()

@@ -1,0 +1,76 @@
+"""HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes: the TCC
+block has 4 counter slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots").
+
+On the GPU box (one command per pass, program directly after `--`, no trace domains next to --pmc):
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 \
+        --no-cpu-baseline --no-roofline --no-host-leg
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py ...   (same)
+then here:
+    python scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r2_pmc_traffic.json
+
+Units and the gfx950 correction (MI355X_MICROARCH.md "HBM"): both counters are in KiB; FETCH_SIZE reports exactly half of
+the bytes of wide (16 B per lane) coalesced reads -- every read of the kernels below is a 16-byte load or an LDS-DMA of 16
+bytes per lane -- so  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Infinity-Cache hits are counted, not excluded.
+Per kernel symbol the per-launch mean over all its dispatches in the run is written, next to the raw counter means."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    """'void (anonymous namespace)::attn_fwd_kernel<false>((anonymous namespace)::AttnArgs)' -> 'attn_fwd_kernel<false>'"""
+    n = re.sub(r'\(anonymous namespace\)::', '', name)
+    n = re.sub(r'^void\s+', '', n)
+    depth, out = 0, ''
+    for ch in n:            # cut the argument list: the first '(' at template depth 0
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            break
+        out += ch
+    return out.strip()
+
+
+def read_pass(d, counter):
+    sums, cnt = defaultdict(float), defaultdict(int)
+    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    assert files, f'no counter_collection.csv under {d}'
+    for f in files:
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                if row['Counter_Name'] != counter:
+                    continue
+                k = short(row['Kernel_Name'])
+                sums[k] += float(row['Counter_Value'])
+                cnt[k] += 1
+    return {k: (sums[k] / cnt[k], cnt[k]) for k in sums}
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fe, wr = read_pass(fetch_dir, 'FETCH_SIZE'), read_pass(write_dir, 'WRITE_SIZE')
+    kernels = {}
+    for k in sorted(set(fe) & set(wr)):
+        f, nf = fe[k]
+        w, nw = wr[k]
+        kernels[k] = {'launches': min(nf, nw), 'FETCH_SIZE_KiB': round(f, 1), 'WRITE_SIZE_KiB': round(w, 1),
+                      'hbm_bytes_per_launch': int((2.0 * f + w) * 1024)}
+    res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over `bench.py --steps 1 --warmup 1`, cfg-3; '
+                     'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request); '
+                     'profiles/r2_pmc_traffic.json',
+           'kernels': kernels}
+    with open(out, 'w') as fh:
+        json.dump(res, fh, indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:25]:
+        print(f"{k[:70]:70s} n={v['launches']:4d}  {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
+
+
+if __name__ == '__main__':
+    main()

@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# no network on the test boxes: a tokenizer / weight lookup must fail fast (and loudly) instead of retrying the hub
+os.environ.setdefault('HF_HUB_OFFLINE', '1')
 
 
 def pytest_configure(config):

@@ -1,0 +1,62 @@
+"""Data-parallel path on the GPU box (`-m gpu`): the RCCL branch of DeviceEnv / BucketedGradReducer on HIP tensors, and the
+two-rank equivalence DP2 == grad-accum 2.  The box has ONE MI355X, so
+  * the RCCL test runs a single rank with a real `nccl` process group (tests/_rccl_child.py, a fresh interpreter started
+    with the torchrun environment before anything touches the GPU) -- ordering compute -> collective -> optimiser, no_sync,
+    parameter broadcast, and a bit-exact train_step through the bucketed asynchronous all-reduce;
+  * the two-rank test puts both ranks on the one device with collectives over gloo (RCCL refuses two ranks per device):
+    scripts/check_dp2_shared_gpu.py, the whole N > 1 control flow against one process with grad_accum_steps = 2.
+ref: task/task_cruller_pretrain.py:181-189,280-283 (DistributedDataParallel + no_sync), framework/device.py:116-135."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    e = dict(os.environ)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    e.update({k: str(v) for k, v in kw.items()})
+    return e
+
+
+def test_rccl_single_rank_reducer_and_train_step():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_child.py')], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env=_env(RANK=0, LOCAL_RANK=0, WORLD_SIZE=1, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port()))
+    assert r.returncode == 0 and 'RCCL_CHILD_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    print(r.stdout[-300:])
+
+
+def test_bench_under_torchrun_single_rank_takes_rccl_path():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1` = the driver's N > 1 command line at N = 1: process group, reducer
+    and the rank-0 JSON line all come from the code `--gpus 8` runs"""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--model', 'cruller_base_960x640', '--batch', '2', '--no-cpu-baseline', '--no-roofline']
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1200, env=_env())
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['config']['parallelism'] == 'dp1' and d.get('collectives') == 'rccl'
+
+
+def test_dp2_on_shared_gpu_equals_grad_accum_2(tmp_path):
+    out = str(tmp_path / 'dp2.pt')
+    script = os.path.join(ROOT, 'scripts', 'check_dp2_shared_gpu.py')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), script, '--out', out]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=_env(CRL_DEBUG_SHARED_GPU=1))
+    assert r.returncode == 0 and os.path.exists(out), (r.stdout[-2000:], r.stderr[-4000:])
+    r = subprocess.run([sys.executable, script, '--reference', out], capture_output=True, text=True, cwd=ROOT, timeout=900, env=_env())
+    assert r.returncode == 0 and 'DP2 == ACCUM2: OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

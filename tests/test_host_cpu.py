@@ -181,18 +181,22 @@ def test_cosine_schedule_matches_golden(golden_dir):
 
 
 def test_loss_scaler_bookkeeping():
-    from pixparse_amd.framework.optim import LossScaler
+    """host side of the device-resident GradScaler: defaults, attach() moves scale / tracker into words 4 / 5 of the optimiser
+    state vector, state_dict round trip (the update rule itself runs in crl_grad_norm_scaled: tests/test_kernels_gpu.py)"""
+    from pixparse_amd.framework.optim import STATE_FLOATS, LossScaler
     sc = LossScaler(growth_interval=3)
-    assert sc.get_scale() == 65536.0
-
-    class Ev:
-        def query(self):
-            return True
-    for flag, want in [(0.0, 65536.0), (0.0, 65536.0), (0.0, 131072.0), (1.0, 65536.0), (0.0, 65536.0)]:
-        sc._pending.append((Ev(), torch.tensor([flag])))
-        sc.update()
-        assert sc.get_scale() == want
-    assert LossScaler(enabled=False).get_scale() == 1.0
+    assert sc.get_scale() == 65536.0 and sc.scale_tensor() is None and sc.growth_interval == 3
+    st = torch.zeros(STATE_FLOATS)
+    sc.attach(st)
+    assert st[4] == 65536.0 and st[5] == 0.0 and sc.scale_tensor().data_ptr() == st[4:5].data_ptr()
+    st[4], st[5] = 1024.0, 2.0            # what the device kernel would leave after backoffs
+    sd = sc.state_dict()
+    assert sd['scale'] == 1024.0 and sd['_growth_tracker'] == 2 and sd['growth_interval'] == 3
+    sc2 = LossScaler().attach(torch.zeros(STATE_FLOATS))
+    sc2.load_state_dict(sd)
+    assert sc2.get_scale() == 1024.0 and sc2.get_growth_tracker() == 2
+    off = LossScaler(enabled=False)
+    assert off.get_scale() == 1.0 and off.attach(torch.zeros(STATE_FLOATS)).scale_tensor() is None
 
 
 class _StubTok:
@@ -520,3 +524,152 @@ def test_eval_rvlcdip_counting_rule_with_scripted_decoder():
     import numpy as np
     b = task.collate_fn([{'image': np.zeros((50, 60, 3), np.uint8), 'label': 3}, None, {'image': np.zeros((50, 60), np.uint8), 'label': 4}])
     assert b['image'].shape == (2, 1, 32, 40) and b['label'].tolist() == [3, 4]
+
+
+# ------------------------------------------------------------------------------------------- pretrained weights / tokenizer
+def _tiny_archs():
+    from pixparse_amd.models.archs import register_arch
+    register_arch('vit', 'vit_pt_test', dict(patch=8, dim=64, depth=2, heads=1, mlp_ratio=2, ln_eps=1e-6, pre_norm=False, mean=(0.5,) * 3, std=(0.5,) * 3))
+    register_arch('bart', 'org/bart_pt_test', dict(d_model=64, heads=1, ffn=128, ln_eps=1e-5, vocab=300, dropout=0.0))
+
+
+def _tiny_cfg(img, fmt, layers, L, enc_pre, dec_pre, path=None):
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    return ModelCfg(image_encoder=ImageEncoderCfg(name='vit_pt_test', image_fmt=fmt, image_size=img, pretrained=enc_pre, pretrained_path=path),
+                    text_decoder=TextDecoderCfg(name='org/bart_pt_test', pretrained=dec_pre, num_decoder_layers=layers, max_length=L,
+                                                pretrained_path=path))
+
+
+def test_pretrained_true_without_weights_is_loud(monkeypatch):
+    """ref image_encoder_timm.py:13-20 / text_decoder_hf.py:25-31 download weights; offline that must never be silent"""
+    from pixparse_amd.models import Cruller
+    from pixparse_amd.models.pretrained import PretrainedWeightsMissing
+    _tiny_archs()
+    monkeypatch.delenv('PIXPARSE_AMD_WEIGHTS', raising=False)
+    with pytest.warns(PretrainedWeightsMissing) as rec:
+        m = Cruller(_tiny_cfg((16, 24), 'RGB', 2, 16, True, True), vocab_size=300)
+    assert len(rec) == 2 and m.pretrained_sources == {'image_encoder': None, 'text_decoder': None}
+    monkeypatch.setenv('PIXPARSE_AMD_STRICT_PRETRAINED', '1')
+    with pytest.raises(FileNotFoundError, match='RANDOM INITIALISATION'):
+        Cruller(_tiny_cfg((16, 24), 'RGB', 2, 16, True, False), vocab_size=300)
+    monkeypatch.delenv('PIXPARSE_AMD_STRICT_PRETRAINED')
+    import warnings as w
+    with w.catch_warnings():
+        w.simplefilter('error')
+        Cruller(_tiny_cfg((16, 24), 'RGB', 2, 16, False, False), vocab_size=300)      # pretrained=False: nothing to say
+
+
+def test_pretrained_weights_load_like_timm_and_hf(tmp_path, monkeypatch):
+    """a synthetic timm ViT checkpoint (3-channel 32x32 -> 4x4 grid) into a 1-channel 16x40 model (adapt_input_conv +
+    resample_abs_pos_embed), and a synthetic full seq2seq BART checkpoint (6 decoder layers, `model.shared.weight`) into a
+    2-layer causal decoder: first n layers, tied + resizable embeddings"""
+    import torch.nn.functional as F
+    from safetensors.torch import save_file
+    from pixparse_amd.layers.engines import BartEngine, ViTEngine
+    from pixparse_amd.models import Cruller
+    from pixparse_amd.models.archs import BART_ARCHS, VIT_ARCHS
+    _tiny_archs()
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    va, ba = VIT_ARCHS['vit_pt_test'], BART_ARCHS['org/bart_pt_test']
+    vit_sd = {k: rnd(*shape) for k, shape in ViTEngine.param_shapes(va, 3, (32, 32))}
+    vit_sd['head.weight'] = rnd(10, 64)                                   # classifier head of the checkpoint: ignored (num_classes=0)
+    V, L_ck = 300, 32
+    bart_sd = {'model.shared.weight': rnd(V, 64), 'model.encoder.layers.0.fc1.weight': rnd(128, 64), 'final_logits_bias': torch.zeros(1, V)}
+    for item in BartEngine.param_shapes(ba, 6, V, L_ck):
+        if not item[0].endswith('embed_tokens.weight'):
+            bart_sd[item[0]] = rnd(*item[1])
+    save_file(vit_sd, str(tmp_path / 'vit_pt_test.safetensors'))
+    save_file(bart_sd, str(tmp_path / 'org--bart_pt_test.safetensors'))
+    monkeypatch.setenv('PIXPARSE_AMD_WEIGHTS', str(tmp_path))
+    import warnings as w
+    with w.catch_warnings():
+        w.simplefilter('error')                                           # found -> no warning
+        m = Cruller(_tiny_cfg((16, 40), 'L', 2, L_ck, True, True))
+    assert m.vocab_size == V and all(p and p.startswith(str(tmp_path)) for p in m.pretrained_sources.values())
+    sd = m.state_dict()
+    e, d = 'image_encoder.trunk.', 'text_decoder.trunk.'
+    assert torch.equal(sd[e + 'blocks.1.mlp.fc2.weight'], vit_sd['blocks.1.mlp.fc2.weight'])
+    assert torch.allclose(sd[e + 'patch_embed.proj.weight'], vit_sd['patch_embed.proj.weight'].sum(1, keepdim=True))
+    pos = vit_sd['pos_embed']
+    grid = F.interpolate(pos[:, 1:].reshape(1, 4, 4, 64).permute(0, 3, 1, 2), size=(2, 5), mode='bicubic', antialias=True, align_corners=False)
+    want = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, 10, 64)], 1)
+    assert sd[e + 'pos_embed'].shape == (1, 11, 64) and torch.allclose(sd[e + 'pos_embed'], want, atol=1e-6)
+    for i in range(2):                                                    # the FIRST n decoder layers of the checkpoint
+        k = f'model.decoder.layers.{i}.encoder_attn.k_proj.weight'
+        assert torch.equal(sd[d + k], bart_sd[k])
+    assert d + 'model.decoder.layers.2.fc1.weight' not in sd
+    assert torch.equal(sd[d + 'model.decoder.embed_tokens.weight'], bart_sd['model.shared.weight'])
+    assert sd[d + 'lm_head.weight'].data_ptr() == sd[d + 'model.decoder.embed_tokens.weight'].data_ptr()
+    assert torch.equal(sd[d + 'model.decoder.embed_positions.weight'], bart_sd['model.decoder.embed_positions.weight'])
+    m.text_decoder.trunk.resize_token_embeddings(V + 2)                   # what the task does after adding 2 tokens (Q7)
+    sd2 = m.state_dict()
+    assert sd2[d + 'lm_head.weight'].shape == (V + 2, 64) and torch.equal(sd2[d + 'lm_head.weight'][:V], bart_sd['model.shared.weight'])
+    assert torch.equal(sd2[e + 'blocks.0.attn.qkv.weight'], vit_sd['blocks.0.attn.qkv.weight'])
+
+
+def test_tokenizer_fallback_is_explicit_or_loud(monkeypatch):
+    from pixparse_amd.tokenizers import BYTE_TOKENIZER, ByteBartTokenizer, TokenizerCfg, TokenizerFallbackWarning, TokenizerHF
+    import warnings as w
+    with w.catch_warnings():
+        w.simplefilter('error')
+        t = TokenizerHF(TokenizerCfg(name=BYTE_TOKENIZER))                # explicit opt-in: silent
+    assert isinstance(t.trunk, ByteBartTokenizer) and len(t.trunk) == 50265
+    with pytest.warns(TokenizerFallbackWarning, match='NOT compatible'):
+        t = TokenizerHF(TokenizerCfg(name='no-such-org/no-such-tokenizer'))
+    assert isinstance(t.trunk, ByteBartTokenizer)
+    monkeypatch.setenv('PIXPARSE_AMD_STRICT_TOKENIZER', '1')
+    with pytest.raises(Exception):
+        TokenizerHF(TokenizerCfg(name='no-such-org/no-such-tokenizer'))
+
+
+def test_head_dim_is_checked():
+    """a head_dim other than 64 must not run silently (kernels index head h at channel 64 h)"""
+    from pixparse_amd import hip, ops
+    from pixparse_amd.layers.arena import ParamArena
+    from pixparse_amd.layers.engines import BartEngine, Buffers, ViTEngine
+    q = torch.zeros(1, 8, 96)
+    with pytest.raises(ValueError, match='head_dim 64'):
+        ops.attn_fwd(q, q, q, q, torch.zeros(1, 3, 8), 3, 0.1, False)
+    with pytest.raises(ValueError, match='head_dim 64'):
+        ViTEngine(dict(patch=8, dim=96, depth=1, heads=3, mlp_ratio=4, ln_eps=1e-6, pre_norm=False), 3, (16, 16), ParamArena(), '', Buffers('cpu'))
+    with pytest.raises(ValueError, match='head_dim 64'):
+        BartEngine(dict(d_model=128, heads=4, ffn=256, ln_eps=1e-5), 1, 100, 16, ParamArena(), '', Buffers('cpu'))
+    hip.load()
+    with pytest.raises(hip.HipLibraryError, match='head_dim is 64'):   # row stride 64 cannot hold 2 heads of 64 channels
+        hip.call('crl_attn_fwd', 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 1, 2, 8, 8, 0.125, 0, None)
+
+
+# ------------------------------------------------------------------------------------------- DeviceEnv under torchrun, one rank
+def test_device_env_single_torchrun_rank_takes_the_distributed_branch():
+    """WORLD_SIZE=1 exported by torchrun still builds a process group (gloo on a CPU env) and an ACTIVE reducer, so
+    `bench.py --gpus 1` under the launcher walks the code `--gpus 8` does; without the launcher env nothing is created"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    code = '''
+import torch, torch.distributed as dist
+from pixparse_amd.framework import DeviceEnv
+from pixparse_amd.framework.reducer import BucketedGradReducer
+from pixparse_amd.layers.arena import ParamArena
+env = DeviceEnv('cpu')
+assert env.distributed and env.world_size == 1 and dist.is_initialized() and dist.get_backend() == 'gloo'
+a = ParamArena(); a.add('w', (1000,)); a.add('b', (10,)); a.materialize('cpu'); a.alloc_training_state()
+r = BucketedGradReducer(a, env.world_size, bucket_bytes=1024, active=env.distributed)
+assert r.active and len(r.buckets) > 2
+a.g.fill_(3.0); r.begin(); r.on_ready('b'); r.on_ready('w'); r.finish()
+assert float(a.g.min()) == 3.0 and r.grad_divisor() == 1.0 and r._next == len(r.buckets)
+r.broadcast_params(0)
+dist.destroy_process_group()
+print('OK')
+'''
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_RANK')}
+    code2 = "from pixparse_amd.framework import DeviceEnv; e = DeviceEnv('cpu'); assert not e.distributed and e.world_size == 1; print('OK')"
+    r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stderr[-2000:]

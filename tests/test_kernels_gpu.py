@@ -520,6 +520,89 @@ def test_grad_norm_adamw(dev, golden_dir):
     assert float(state[2]) == 1.0 and torch.equal(p, before)
 
 
+def test_adamw_with_device_gradscaler_vs_torch(dev):
+    """ArenaAdamW + LossScaler (scale, growth tracker and step counter on the device) against torch.optim.AdamW +
+    torch.amp.GradScaler + clip_grad_norm_: six updates with an inf injected into the gradients of update 2 -- the skipped
+    step must not advance the bias-correction exponent, the very next update must already run with the halved scale, and
+    the scale must grow again after growth_interval clean steps (ref: task/task_cruller_pretrain.py:205-207,259-278)."""
+    from pixparse_amd.framework.optim import ArenaAdamW, LossScaler
+    from pixparse_amd.layers.arena import ParamArena
+    torch.manual_seed(0)
+    n = 3 * 4096 + 64
+    arena = ParamArena()
+    arena.add('w', (n,))
+    arena.materialize(dev)
+    arena.p.copy_(torch.randn(n, device=dev) * 0.1)
+    lr, betas, eps = 1e-2, (0.9, 0.98), 1e-6
+    opt = ArenaAdamW(arena, lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+    arena.alloc_shadow()
+    sc = LossScaler(init_scale=1024.0, growth_interval=2).attach(opt.state)
+    pr = torch.nn.Parameter(arena.p.clone())
+    topt = torch.optim.AdamW([pr], lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+    tsc = torch.amp.GradScaler('cuda', init_scale=1024.0, growth_interval=2)
+    grads = [torch.randn(n, device=dev) * (1.0 + i) for i in range(6)]
+    grads[1][17] = float('inf')
+    want_scales = [1024.0, 512.0, 512.0, 1024.0, 1024.0, 2048.0]      # after each update()
+    for i, g in enumerate(grads):
+        s_dev = float(opt.state[4])
+        assert s_dev == float(tsc.get_scale()), (i, s_dev, tsc.get_scale())
+        arena.g.copy_(g * s_dev)                       # what backward leaves: gradients of the scaled loss
+        opt.step(clip_norm=1.0, zero_grad=True, scaler=sc, grad_divisor=1.0)
+        pr.grad = g * tsc.get_scale()
+        tsc.unscale_(topt)
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        tsc.step(topt)
+        tsc.update()
+        assert float(opt.found_inf()) == (1.0 if i == 1 else 0.0)
+        assert sc.get_scale() == want_scales[i] == float(tsc.get_scale()), (i, sc.get_scale(), tsc.get_scale())
+        assert opt.step_count == (i + 1 if i < 1 else i), (i, opt.step_count)   # the skipped update does not count
+        close(arena.p, pr.detach(), 2e-6, 1e-7, f'update {i}')
+        assert torch.equal(arena.pb, arena.p.to(BF16)) and float(arena.g.abs().max()) == 0.0
+    assert sc.state_dict()['_growth_tracker'] == 0 and opt.state_dict()['step'] == 5
+
+
+def test_out_of_range_ids_and_targets_do_not_touch_memory(dev):
+    """torch raises a device assert for an out-of-vocabulary id / target; here the damage is contained and LOUD:
+    embedding rows and the loss turn NaN, the scatter skips the row, nothing outside the tables is read or written"""
+    from pixparse_amd import ops
+    B, T, D, V = 2, 8, 64, 50
+    tok = torch.randn(V, D, device=dev)
+    pos = torch.randn(T + 2, D, device=dev)
+    ids = torch.randint(0, V, (B, T), device=dev)
+    ids[0, 3] = V + 5
+    ids[1, 0] = -1
+    out = torch.zeros(B * T, D, device=dev)
+    ops.embed_fwd(ids, tok, pos, out, 2)
+    bad = torch.tensor([3, 8], device=dev)
+    assert torch.isnan(out[bad]).all() and torch.isfinite(out[[0, 1, 2, 4, 9]]).all()
+    guard = torch.zeros(V + 16, D, device=dev)        # the rows behind the table stay zero
+    dpos = torch.zeros(T + 2, D, device=dev)
+    dt = torch.ones(B * T, D, device=dev)
+    ops.embed_bwd(ids, dt, guard[:V], dpos, 2, False)
+    assert float(guard[V:].abs().max()) == 0.0 and float(guard[:V].sum()) == (B * T - 2) * D
+    M, Vp = 6, 64
+    logits = torch.randn(M, Vp, device=dev).to(BF16)
+    target = torch.tensor([1, 2, Vp + 100, -100, 3, 49], device=dev)
+    loss = torch.zeros(1, device=dev); nv = torch.zeros(1, dtype=torch.int32, device=dev); rl = torch.empty(M, device=dev)
+    ops.cross_entropy(logits, target, V, 1.0, 1.0, loss, nv, rl, logits)
+    assert math.isnan(float(loss)) and float(logits[2].abs().max()) == 0.0 and torch.isfinite(logits.float()).all()
+
+
+def test_cross_entropy_device_side_scale(dev):
+    """grad_mul_dev: the loss scale is read on the device (GradScaler word state[4])"""
+    from pixparse_amd import ops
+    M, V, Vp = 16, 100, 128
+    logits = (torch.randn(M, Vp, device=dev) * 2).to(BF16)
+    target = torch.randint(0, V, (M,), device=dev)
+    a, b = logits.clone(), logits.clone()
+    loss = torch.zeros(1, device=dev); nv = torch.zeros(1, dtype=torch.int32, device=dev); rl = torch.empty(M, device=dev)
+    ops.cross_entropy(a, target, V, 1.0, 0.5 * 256.0, loss, nv, rl, a)
+    la = float(loss)
+    scale = torch.tensor([256.0], device=dev)
+    ops.cross_entropy(b, target, V, 1.0, 0.5, loss, nv, rl, b, scale)
+    assert torch.equal(a, b) and float(loss) == la
+
+
 @pytest.mark.parametrize('H,W,C,Ho,Wo', [(877, 620, 3, 1280, 960), (1754, 1240, 1, 960, 640), (300, 200, 3, 224, 224)])
 def test_gpu_image_preprocess(dev, H, W, C, Ho, Wo):
     """uint8 page -> ToTensor -> bicubic antialias Resize -> Normalize on the GPU vs the same ops in torch (CPU)"""

@@ -188,9 +188,22 @@ def test_app_train_checkpoint_roundtrip(dev, tmp_path):
     k = 'image_encoder.trunk.layers.2.blocks.3.mlp.fc1.weight'
     assert k in sd1 and 'text_decoder.trunk.lm_head.weight' in sd1 and sd1[k].shape == (1536, 384)
     assert not torch.equal(sd0[k], sd1[k]) and torch.isfinite(sd1[k]).all()
-    model = Cruller(get_model_config('cruller_small'), vocab_size=50267)
-    model.load_state_dict({'module.' + n: v for n, v in sd1.items()} and sd1)
+    mc = get_model_config('cruller_small')
+    mc.image_encoder.pretrained = mc.text_decoder.pretrained = False
+    model = Cruller(mc, vocab_size=50267)
+    model.load_state_dict(sd1)
     assert torch.equal(model.state_dict()[k], sd1[k])
+    # a DistributedDataParallel checkpoint carries 'module.' prefixes (ref app/eval.py:135): the task-level loader strips them
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    mc2 = get_model_config('cruller_small')
+    mc2.image_encoder.pretrained = mc2.text_decoder.pretrained = False
+    task = TaskCrullerPretrain(TaskCrullerPretrainCfg(dtype='bfloat16', model=mc2), DeviceEnv())
+    task.train_setup(num_batches_per_interval=2)
+    state = task.training_state()
+    state['model'] = {'module.' + n: v for n, v in sd1.items()}
+    task.load_training_state(state)
+    assert torch.equal(task.model.state_dict()[k].cpu(), sd1[k])
 
 
 def test_resume_continues_identically(dev):
@@ -399,7 +412,7 @@ def test_eval_rvlcdip_task_step_gpu(dev):
 def test_bench_json_contract(dev, capsys, monkeypatch):
     """bench.py prints ONE JSON line with the driver's keys + roofline (live) on a small config, in-process"""
     import importlib, sys as _sys
-    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--model', 'cruller_base_960x640', '--batch', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'])
+    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--model', 'cruller_base_960x640', '--batch', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'])
     bench = importlib.import_module('bench')
     bench.main()
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
@@ -411,3 +424,6 @@ def test_bench_json_contract(dev, capsys, monkeypatch):
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and r['kernel'].startswith('attn_') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert r['launches_timed'] > 0 and r['kernels'][r['kernel']]['ms_per_launch'] == r['ms_per_launch']
+    assert 500 < r['peak_measured'] < 2500 and abs(r['frac_measured'] - r['achieved'] / r['peak_measured']) < 1e-3
+    h = d['host_inputs']                                   # the reference boundary: host batches, H2D inside the step
+    assert h['unit'] == 'docs/s' and 0 < h['value'] and d['collectives'] == 'none'

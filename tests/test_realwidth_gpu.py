@@ -1,0 +1,266 @@
+"""HIP path vs the CPU oracle at the REAL widths and depths of BASELINE.json's configs (`-m gpu`).
+
+tests/test_model_gpu.py pins every engine against the oracle at dim 128 / depth 2; here the same comparison runs on the
+architectures the headline is quoted on (VERDICT r1 "Next round" item 1):
+
+ (a) full depth, small geometry      ViT-L/14 CLIP (24 blocks, D 1024, 16 heads) + BART-large 10 layers, V = 50267, on a
+                                     224x168 image (193 encoder tokens), 128-token targets, batch 2: loss, every parameter
+                                     gradient and the total gradient norm against the oracle's bf16 policy, and the drift of
+                                     both against the oracle's fp32 policy;
+ (b) full length, truncated depth    cfg-3 widths at N = 6189 / T = 1023 (the exact sample bench.py's cpu_baseline times):
+                                     2 encoder blocks + 1 decoder layer, batch 1: loss, d(encoder output), weight gradients;
+ (c) cfg-2 (cruller_base 960x640, batch 8): determinism, expected initial loss, truncated-depth oracle compare at N = 2401;
+ (d) cfg-5 (cruller_large_6layers, 2560x1920 -> N = 24935, T = 2047, micro-batch 2, grad-accum 4): finite, deterministic,
+     accumulation-step bookkeeping, attention rows at N = 24935 against fp32 recomputation.
+
+Reference call sites: task/task_cruller_pretrain.py:247-257 (the `_forward` closure), models/cruller.py:14-21.
+Tolerances are the ones of tests/test_model_gpu.py: loss 1e-3 relative (BASELINE.json north_star), 5 % relative L2 per
+gradient tensor, 2 % on the total gradient norm.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+VOCAB = 50267
+VIT_L, BART_L = 'vit_large_patch14_clip_224.datacompxl', 'facebook/bart-large'
+VIT_B, BART_B = 'vit_base_patch16_224', 'facebook/bart-base'
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _truncated(enc_name, depth):
+    """register `enc_name` cut to `depth` blocks on both sides (product arch table + oracle arch table)"""
+    from oracle import ref_cpu as R
+    from pixparse_amd.models.archs import VIT_ARCHS, register_arch
+    name = f'{enc_name}@depth{depth}'
+    arch = dict(VIT_ARCHS[enc_name], depth=depth)
+    register_arch('vit', name, arch)
+    R.VIT_ARCHS[name] = dict(R.VIT_ARCHS[enc_name], depth=depth)
+    return name
+
+
+def _model_cfg(enc, img, fmt, dec, layers, L):
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    return ModelCfg(image_encoder=ImageEncoderCfg(name=enc, image_fmt=fmt, image_size=img, pretrained=False),
+                    text_decoder=TextDecoderCfg(name=dec, pretrained=False, num_decoder_layers=layers, max_length=L))
+
+
+def _build_pair(dev, enc, img, fmt, dec, layers, L, seed):
+    """(HIP model on the device, oracle spec, shared fp32 parameters): both sides start from the oracle's deterministic
+    init (N(0, .02) everywhere, biases included, LayerNorm scales 1 + N(0, .02))"""
+    from oracle import ref_cpu as R
+    from pixparse_amd.models import Cruller
+    spec = R.ModelSpec(enc, dec, layers, L, img, 1 if fmt == 'L' else 3, vocab=VOCAB)
+    params = R.init_params(spec, seed)
+    model = Cruller(_model_cfg(enc, img, fmt, dec, layers, L), vocab_size=VOCAB)
+    sd = dict(params)
+    sd['text_decoder.trunk.lm_head.weight'] = params['text_decoder.trunk.model.decoder.embed_tokens.weight']
+    model.load_state_dict(sd)
+    assert {k: tuple(v.shape) for k, v in params.items()} == spec.param_shapes()
+    model.to(dev)
+    model.arena.alloc_training_state()
+    return model, spec, params
+
+
+def _oracle_grads(spec, params, image, ti, tt, policy, fast_attn=False):
+    from oracle import ref_cpu as R
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    loss = R.cruller_loss(op, spec, image, ti, tt, policy, fast_attn=fast_attn)
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in op.items()}
+
+
+def _compare_grads(model, ograds, tol_tensor, tol_total):
+    worst = []
+    for k, og in ograds.items():
+        g = model.arena.grad(k)
+        if k.endswith('k_proj.bias'):   # identically zero gradient (softmax shift invariance): rounding noise on both sides
+            qn = float(ograds[k.replace('k_proj', 'q_proj')].norm())
+            assert float(g.norm()) < 5e-2 * qn + 1e-12, k
+            continue
+        worst.append((rel(g, og), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < tol_tensor, worst[:6]
+    tot = math.sqrt(sum(float((g.float() ** 2).sum()) for g in ograds.values()))
+    mine = float(model.arena.g.norm())
+    assert abs(mine - tot) / tot < tol_total, (mine, tot)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ (a)
+def test_full_depth_real_width_vs_oracle(dev):
+    """ViT-L/14 CLIP x 24 + BART-large x 10 at their real widths: bf16 error growth through 24 pre-LN + 10 post-LN layers
+    at D = 1024 stays inside the tolerances asserted at toy width"""
+    from oracle import ref_cpu as R
+    img, L, B = (224, 168), 128, 2
+    model, spec, params = _build_pair(dev, VIT_L, img, 'RGB', BART_L, 10, L, seed=11)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=5, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    with torch.no_grad():
+        ologits = R.cruller_forward(params, spec, image, ti, 'bf16')
+        loss32 = float(R.cross_entropy(R.cruller_forward(params, spec, image, ti, 'fp32'), tt))
+    oloss, ograds = _oracle_grads(spec, params, image, ti, tt, 'bf16')
+    out = model(image.to(dev), ti.to(dev))
+    assert out['logits'].shape == (B, L - 1, VOCAB)
+    assert rel(out['logits'], ologits) < 2e-2
+    loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    assert abs(loss - oloss) / oloss < 1e-3, (loss, oloss)
+    # drift against exact arithmetic: the HIP path may not be further from fp32 than the reference's own bf16 policy is
+    # (plus the 1e-3 the two bf16 executions are allowed to differ by)
+    assert abs(loss - loss32) <= abs(oloss - loss32) + 1e-3 * loss32, (loss, oloss, loss32)
+    model.backward()
+    worst = _compare_grads(model, ograds, 5e-2, 2e-2)
+    print(f'\n[a] loss hip {loss:.6f} oracle-bf16 {oloss:.6f} oracle-fp32 {loss32:.6f}; worst grad rel-L2 {worst[0]}')
+
+
+# ------------------------------------------------------------------------------------------------ (b)
+def test_full_length_truncated_depth_vs_oracle(dev):
+    """cfg-3 widths at the full sequence lengths (N = 6189 encoder tokens = 97 key tiles with a ragged tail, T = 1023):
+    2 encoder blocks + 1 decoder layer + the 50267-column LM head, batch 1. The oracle uses torch's fused CPU SDPA for
+    the 6189^2 attention (bench.py's cpu_baseline sample), everything else is the parity restatement."""
+    from oracle import ref_cpu as R
+    enc = _truncated(VIT_L, 2)
+    img, L, B = (1280, 960), 1024, 1
+    model, spec, params = _build_pair(dev, enc, img, 'RGB', BART_L, 1, L, seed=12)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=6, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    # oracle with the encoder output kept, so that d(loss)/d(encoder output) can be compared as well
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    oenc = R.vit_forward(op, spec.enc_arch, image, 'bf16', prefix='image_encoder.trunk.', fast_attn=True)
+    oenc.retain_grad()
+    ologits = R.bart_decoder_forward(op, spec.dec_arch, 1, ti, oenc, 'bf16', prefix='text_decoder.trunk.', fast_attn=True)
+    oloss = R.cross_entropy(ologits, tt)
+    oloss.backward()
+    loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    assert abs(loss - float(oloss)) / float(oloss) < 1e-3, (loss, float(oloss))
+    e, _, bufs = model._engines
+    assert e.N == 6189 and bufs.t['vit.norm.y32'].shape == (6189, 1024)
+    assert rel(bufs.t['vit.norm.y32'], oenc.detach()[0]) < 1e-2
+    model.backward()
+    assert rel(bufs.t['denc'], oenc.grad[0]) < 5e-2
+    ograds = {k: v.grad for k, v in op.items()}
+    worst = _compare_grads(model, ograds, 5e-2, 2e-2)
+    print(f'\n[b] loss hip {loss:.6f} oracle {float(oloss):.6f}; worst grad rel-L2 {worst[0]}')
+
+
+# ------------------------------------------------------------------------------------------------ (c)
+def _run_task(model_name, batch, steps, accum=1, seed0=100):
+    from pixparse_amd.data import synthetic_batch
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.models import get_model_config
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    mc = get_model_config(model_name)
+    mc.image_encoder.pretrained = False
+    mc.text_decoder.pretrained = False
+    cfg = TaskCrullerPretrainCfg(num_intervals=1, num_warmup_intervals=0, eval_frequency=10 ** 9, dtype='bfloat16',
+                                 opt=OptimizationCfg(learning_rate=1e-4, clip_grad_value=1.0, clip_grad_mode='norm', grad_accum_steps=accum),
+                                 model=mc)
+    torch.manual_seed(0)
+    task = TaskCrullerPretrain(cfg, DeviceEnv())
+    task.train_setup(num_batches_per_interval=max(steps, 2 * accum))
+    task.train_interval_start()
+    m = task.model
+    out = []
+    for i in range(steps):
+        sample = synthetic_batch(batch, m.in_chans, m.img_size, m.max_length, task.vocab_size, seed=seed0 + i)
+        task.train_step(sample)
+        out.append((float(task.last_loss), float(task.optimizer.grad_norm()), task.step))
+    shapes = dict(N=m._engines[0].N, T=m._engines[1].T, act_gb=m.activation_bytes() / 2 ** 30)
+    del task
+    torch.cuda.empty_cache()
+    return out, shapes
+
+
+def test_cfg2_base_batch8_deterministic_and_expected_loss(dev):
+    """BASELINE.json configs[1]: cruller_base (ViT-B/16 @ 960x640x1 -> 2401 tokens, BART-base 4L, 512-token targets), batch 8"""
+    a, sa = _run_task('cruller_base_960x640', 8, 2)
+    b, _ = _run_task('cruller_base_960x640', 8, 2)
+    assert a == b, (a, b)
+    assert sa['N'] == 2401 and sa['T'] == 511
+    expect = math.log(VOCAB) + 0.5 * (0.02 * math.sqrt(768)) ** 2   # tied head on unit-variance LN outputs
+    assert abs(a[0][0] - expect) < 0.05 and all(math.isfinite(v) for s in a for v in s[:2]), (a, expect)
+    assert [s[2] for s in a] == [1, 2]
+
+
+def test_cfg2_full_length_truncated_depth_vs_oracle(dev):
+    """cfg-2 widths (D 768, 12 heads, 1-channel 16x16 patches: K = 256) at N = 2401 / T = 511, 2 + 1 layers, batch 2"""
+    from oracle import ref_cpu as R
+    enc = _truncated(VIT_B, 2)
+    img, L, B = (960, 640), 512, 2
+    model, spec, params = _build_pair(dev, enc, img, 'L', BART_B, 1, L, seed=13)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=7, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    oloss, ograds = _oracle_grads(spec, params, image, ti, tt, 'bf16', fast_attn=True)
+    loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    assert abs(loss - oloss) / oloss < 1e-3, (loss, oloss)
+    model.backward()
+    worst = _compare_grads(model, ograds, 5e-2, 2e-2)
+    print(f'\n[c] loss hip {loss:.6f} oracle {oloss:.6f}; worst grad rel-L2 {worst[0]}')
+
+
+# ------------------------------------------------------------------------------------------------ (d)
+def test_cfg5_6layers_2560x1920_accum4(dev):
+    """BASELINE.json configs[4] on one GPU: cruller_large_6layers, 2560x1920 -> N = 24935 encoder tokens, 2048-token
+    targets, micro-batch 2, grad-accum 4: one optimiser update after four micro-steps, finite and bit-reproducible"""
+    a, sa = _run_task('cruller_large_6layers', 2, 4, accum=4)
+    assert sa['N'] == 24935 and sa['T'] == 2047, sa
+    assert [s[2] for s in a] == [0, 0, 0, 1]                      # `step` advances on the fourth micro-step only
+    assert all(math.isfinite(s[0]) for s in a) and math.isfinite(a[-1][1]) and a[-1][1] > 0
+    expect = (math.log(VOCAB) + 0.5 * (0.02 * math.sqrt(1024)) ** 2) / 4       # loss / grad_accum_steps (ref :255-256)
+    assert all(abs(s[0] - expect) < 0.02 for s in a), (a, expect)
+    b, _ = _run_task('cruller_large_6layers', 2, 4, accum=4)
+    assert a == b, (a, b)
+
+
+def test_attention_rows_at_24935_tokens(dev):
+    """the cfg-5 encoder attention (390 key tiles, ragged tail of 39 keys): sampled query rows of the forward and of dQ,
+    sampled keys of dK / dV against fp32 recomputation; sum_k dV = sum_q dO P^T column identity"""
+    from pixparse_amd import ops
+    B, H, N, d = 1, 2, 24935, 64
+    D, scale = H * d, d ** -0.5
+    g = torch.Generator(device=dev).manual_seed(3)
+    qkv = torch.randn(B, N, 3 * D, generator=g, device=dev).to(BF16)
+    q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    o = torch.empty(B, N, D, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, N, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False)
+    hd = lambda t: t.float().reshape(B, N, H, d).transpose(1, 2)
+    Q, K, V, O = hd(q), hd(k), hd(v), hd(o)
+    rows = torch.cat([torch.randperm(N, generator=torch.Generator().manual_seed(0))[:62], torch.tensor([0, N - 1])]).to(dev)
+    S = Q[:, :, rows] @ K.transpose(-1, -2) * scale
+    P = torch.softmax(S, -1)
+    ref_o = P.to(BF16).float() @ V
+    assert float((O[:, :, rows] - ref_o).abs().max()) < 2e-2
+    assert float((lse[:, :, rows] - torch.logsumexp(S, -1)).abs().max()) < 3e-3
+    d_o = torch.randn(B, N, D, generator=g, device=dev).to(BF16)
+    dqkv = torch.zeros(B, N, 3 * D, dtype=BF16, device=dev)
+    delta = torch.empty(2, B, H, N, device=dev)
+    ops.attn_bwd(q, k, v, o, d_o, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False)
+    dO = hd(d_o)
+    dl = (dO * O).sum(-1)                                                       # [B, H, N]
+    dP = dO[:, :, rows] @ V.transpose(-1, -2)
+    dS = P * (dP - dl[:, :, rows, None])
+    ref_dq = (dS.to(BF16).float() @ K) * scale
+    got_dq = hd(dqkv[:, :, :D])[:, :, rows]
+    assert rel(got_dq, ref_dq) < 2e-2
+    keys = torch.cat([torch.randperm(N, generator=torch.Generator().manual_seed(1))[:62], torch.tensor([0, N - 1])]).to(dev)
+    St = (Q @ K[:, :, keys].transpose(-1, -2)) * scale                          # [B, H, N, 64]
+    Pt = torch.exp(St - lse[..., None])
+    ref_dv = Pt.to(BF16).float().transpose(-1, -2) @ dO
+    dPt = dO @ V[:, :, keys].transpose(-1, -2)
+    dSt = Pt * (dPt - dl[..., None])
+    ref_dk = (dSt.to(BF16).float().transpose(-1, -2) @ Q) * scale
+    assert rel(hd(dqkv[:, :, 2 * D:])[:, :, keys], ref_dv) < 2e-2
+    assert rel(hd(dqkv[:, :, D:2 * D])[:, :, keys], ref_dk) < 2e-2
