@@ -50,8 +50,9 @@ enum { CRL_EPI_BF16 = 0, CRL_EPI_BF16_GELU = 1, CRL_EPI_BF16_DGELU = 2, CRL_EPI_
 /* ws (optional, >= crl_gemm_ws_bytes(...)): fp32 scratch that lets the wgrad layout split its long
  * contraction over several workgroups per output tile (deterministic slab reduce, no atomics). */
 size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K);
-/* kernel selection override for tests: 0 = auto (256x256 8-phase kernel when it fills the chip, else 128x128),
- * 1 = always 128x128, 2 = 256x256 whenever legal. */
+/* kernel selection override for tests / A-B runs: 0 = auto (the 256-row kernels when they fill the chip, else 128x128),
+ * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent
+ * workgroups per CU: epilogues overlap main loops) for the NT / NN layouts whenever legal. */
 int crl_gemm_set_policy(int policy);
 int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -96,12 +97,15 @@ int crl_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 /* dy = dy_f32 (optional) + float(dy_bf16) (optional).  dx_f32 (+)= LN'(dy) when dx_accumulate;
  * dx_bf16 (optional) receives a bf16 copy of the final value written to dx_f32 (the accumulated
  * sum when dx_accumulate) -- it is the gradient the next GEMM backward consumes.
- * dgamma/dbeta are accumulated (+=) when acc_wgrad else overwritten.  ws >= crl_layernorm_bwd_ws_bytes(D). */
+ * dx_colsum (optional, [D]): column sums over the M rows of the bf16 values written to dx_bf16 = the bias gradient of the
+ *   Linear whose output gradient dx_bf16 is (nn.Linear backward: db = sum_rows dY) -- fused here because the rows pass
+ *   through registers anyway; replaces a crl_colsum_bf16 pass over dx_bf16.
+ * dgamma/dbeta/dx_colsum are accumulated (+=) when acc_wgrad else overwritten.  ws >= crl_layernorm_bwd_ws_bytes(D). */
 size_t crl_layernorm_bwd_ws_bytes(int64_t D);
 int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, const float* gamma,
                       const float* mean, const float* rstd, int64_t M, int64_t D,
                       float* dx_f32, int dx_accumulate, void* dx_bf16,
-                      float* dgamma, float* dbeta, int acc_wgrad, void* ws, void* stream);
+                      float* dgamma, float* dbeta, float* dx_colsum, int acc_wgrad, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- flash attention, head_dim 64
  * replaces F.scaled_dot_product_attention: timm Attention (ViT global MHSA, non-causal),

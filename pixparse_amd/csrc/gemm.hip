@@ -180,12 +180,17 @@ int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
 }  // namespace
 
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
+int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t s);
 
 // Kernel / split-K plan.  big = 256x256 8-phase kernel (one workgroup per CU) when it fills the chip, else the
 // 128x128 kernel.  The wgrad layout (few output tiles, very long contraction) cuts the contraction into nsplit
 // chunks: partial tiles go to fp32 slabs in the caller's scratch, then one deterministic reduce pass.
 struct Plan { bool big; int nsplit; int64_t chunk; };
-static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (tests)
+static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel, 3 force the 256x128 two-per-CU kernel (tests, A/B)
+#ifndef G_AUTO_2X
+#define G_AUTO_2X 1      // auto policy: very wide NT outputs (the LM head: N = 50304) go to the 256x128 two-workgroups-per-CU kernel
+#endif                   // (gemm2x.hip): same-box A/B +8 % there, +15 % at 8192^3; the K = 1024 encoder shapes are faster on the
+                         // 256x256 kernel + wave-quantisation split (A/B table in DESIGN.md), so they stay there
 static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K, bool allow_split) {
   Plan p{false, 1, 0};
   const int64_t nk = (K + 63) / 64;
@@ -212,7 +217,7 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
 }
 
 extern "C" int crl_gemm_set_policy(int policy) {
-  if (policy < 0 || policy > 2) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
+  if (policy < 0 || policy > 3) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
   g_policy = policy;
   return 0;
 }
@@ -260,6 +265,14 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   if (bk == 32) { p.big = false; p.nsplit = 1; p.chunk = (K + 31) / 32; }
   a.kchunk = (int)p.chunk;
   a.slab_stride = 0;
+  {
+    // 256x128 tiles, two independent workgroups per CU: one's epilogue runs under the other's MFMA loop (gemm2x.hip)
+    const bool can2x = layout != CRL_TN && bk == 64 && p.nsplit == 1 && M >= 128 && N >= 64;
+    if (can2x && (g_policy == 3 || (g_policy == 0 && G_AUTO_2X && p.big && layout == CRL_NT && N >= 8192))) {
+      a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 127) / 128);
+      return crl_gemm2x_launch(layout, epilogue, a, s);
+    }
+  }
   if (p.big) { a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 255) / 256); }
   if (p.nsplit > 1) {
     GemmArgs b = a;

@@ -22,6 +22,7 @@
 // data has been consumed by MFMAs before the closing barrier of that phase.
 #include <type_traits>
 #include "gemm_common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 using namespace gemmc;
@@ -217,110 +218,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
     issue(1, 0); issue(1, 1);
   }
-  const int li = lane_e & 15, lq = lane_e >> 4;
-  // Branch-free loads: every epilogue operand (bias, residual, saved pre-activation, accumulated gradient) of a row's four
-  // column groups is fetched from CLAMPED coordinates before anything is stored, so the loads of a row -- and, registers
-  // permitting, of the next row -- are in flight together; only the stores are predicated. (With the bounds checks as
-  // branches around each group, hipcc serialised load -> wait -> store 32 times per lane: ~45 us of latency per tile.)
-  constexpr bool READS_TILE = (EPI == CRL_EPI_BF16_DGELU || EPI == CRL_EPI_F32_RESID || EPI == CRL_EPI_F32_ACC);
-  auto epilogue = [&](auto has_bias_c) {
-  constexpr bool HAS_BIAS = decltype(has_bias_c)::value;
-#pragma unroll
-  for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0e + 128 * qm + 64 * wr + 16 * i + li;
-      const bool m_ok = m < g.M;
-      const size_t mc = (size_t)(m_ok ? m : g.M - 1);
-      int nn[4];
-      bool ok[4];
-      float4 bv[4], rv[4];
-      uint2 hv[4];
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int n = n0e + 128 * (c4 >> 1) + 32 * wc + 16 * (c4 & 1) + 4 * lq;
-        ok[c4] = m_ok && n < g.N;
-        nn[c4] = n < g.N ? n : g.N - 4;
-        if constexpr (HAS_BIAS) bv[c4] = *reinterpret_cast<const float4*>(g.bias + nn[c4]);
-        if constexpr (EPI == CRL_EPI_BF16_DGELU) hv[c4] = *reinterpret_cast<const uint2*>((const u16*)g.aux + mc * g.ldaux + nn[c4]);
-        if constexpr (EPI == CRL_EPI_F32_RESID) rv[c4] = *reinterpret_cast<const float4*>(g.resid + mc * g.ldr + nn[c4]);
-        if constexpr (EPI == CRL_EPI_F32_ACC) rv[c4] = *reinterpret_cast<const float4*>((const float*)g.C + mc * g.ldc + nn[c4]);
-      }
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const f32x4 a4 = acc[qm][c4 >> 1][i][c4 & 1];
-        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-        const size_t n = (size_t)nn[c4];
-        if constexpr (HAS_BIAS) {
-          v[0] += round_bf(bv[c4].x); v[1] += round_bf(bv[c4].y); v[2] += round_bf(bv[c4].z); v[3] += round_bf(bv[c4].w);
-        }
-        if constexpr (EPI == CRL_EPI_BF16) {
-          if (ok[c4]) *reinterpret_cast<uint2*>((u16*)g.C + mc * g.ldc + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
-          float h[4], y[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
-          if (ok[c4]) {
-            *reinterpret_cast<uint2*>((u16*)g.aux + mc * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-            *reinterpret_cast<uint2*>((u16*)g.C + mc * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-          }
-        } else if constexpr (EPI == CRL_EPI_BF16_DGELU) {
-          const uint2 hh = hv[c4];
-          const float h0 = bf2f(hh.x & 0xffff), h1 = bf2f(hh.x >> 16), h2 = bf2f(hh.y & 0xffff), h3 = bf2f(hh.y >> 16);
-          const float y0 = round_bf(v[0]) * dgelu_f(h0), y1 = round_bf(v[1]) * dgelu_f(h1);
-          const float y2 = round_bf(v[2]) * dgelu_f(h2), y3 = round_bf(v[3]) * dgelu_f(h3);
-          if (ok[c4]) *reinterpret_cast<uint2*>((u16*)g.C + mc * g.ldc + n) = uint2{pack_bf2(y0, y1), pack_bf2(y2, y3)};
-        } else if constexpr (EPI == CRL_EPI_F32_RESID) {
-          const float4 r = rv[c4];
-          if (ok[c4]) *reinterpret_cast<float4*>((float*)g.C + mc * g.ldc + n) =
-              float4{r.x + round_bf(v[0]), r.y + round_bf(v[1]), r.z + round_bf(v[2]), r.w + round_bf(v[3])};
-        } else if constexpr (EPI == CRL_EPI_F32) {
-          if (ok[c4]) *reinterpret_cast<float4*>((float*)g.C + blockIdx.y * g.slab_stride + mc * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
-        } else {
-          const float4 o = rv[c4];
-          if (ok[c4]) *reinterpret_cast<float4*>((float*)g.C + mc * g.ldc + n) = float4{o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]};
-        }
-      }
-    }
-  };
-  constexpr bool BIAS_EPI = (EPI == CRL_EPI_BF16 || EPI == CRL_EPI_BF16_GELU || EPI == CRL_EPI_F32_RESID);
-  if constexpr (READS_TILE) {
-    if (BIAS_EPI && g.bias) epilogue(std::true_type{}); else epilogue(std::false_type{});
-  } else {
-    // store-only epilogues (bias from L1, nothing tile-sized to read): group by group; same-box A/B has this form 1-3 %
-    // ahead of the batched one for them
-#pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0e + 128 * qm + 64 * wr + 16 * i + li;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-          const int n = n0e + 128 * (c4 >> 1) + 32 * wc + 16 * (c4 & 1) + 4 * lq;
-          if (n >= g.N) continue;
-          const f32x4 a4 = acc[qm][c4 >> 1][i][c4 & 1];
-          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-          if constexpr (BIAS_EPI) {
-            if (g.bias) {
-              const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-              v[0] += round_bf(b.x); v[1] += round_bf(b.y); v[2] += round_bf(b.z); v[3] += round_bf(b.w);
-            }
-          }
-          if constexpr (EPI == CRL_EPI_BF16) {
-            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
-            float h[4], y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
-            *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-          } else {   // CRL_EPI_F32: split-K slab
-            *reinterpret_cast<float4*>((float*)g.C + blockIdx.y * g.slab_stride + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};
-          }
-        }
-      }
-  }
+  epilogue_tile<EPI, 128>(g, acc, m0e, n0e, wr, wc, lane_e, (size_t)blockIdx.y * g.slab_stride);
   if (!has_next) break;
   logical = next_logical;
   first_tile = false;

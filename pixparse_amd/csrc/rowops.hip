@@ -76,14 +76,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      int M, int D, float* __restrict__ dx32, int dx_acc,
-                                                     u16* __restrict__ dx16, float* __restrict__ ws) {
+                                                     u16* __restrict__ dx16, float* __restrict__ ws, int want_colsum) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][2][D]
+  float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][NP][D], NP = 2 (+1 with the output column sums)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
-  float4 ag[LN_MAXV], ab[LN_MAXV];
+  const int NP = want_colsum ? 3 : 2;
+  // ao: column sums of the bf16 gradient this kernel EMITS (dx16) = the bias gradient of the Linear whose output
+  // gradient it is -- the rows are in registers anyway, so the separate colsum pass over dx16 disappears
+  float4 ag[LN_MAXV], ab[LN_MAXV], ao[LN_MAXV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) { ag[i] = float4{0, 0, 0, 0}; ab[i] = float4{0, 0, 0, 0}; }
+  for (int i = 0; i < LN_MAXV; ++i) { ag[i] = float4{0, 0, 0, 0}; ab[i] = float4{0, 0, 0, 0}; ao[i] = float4{0, 0, 0, 0}; }
   for (int row = blockIdx.x * 4 + wave; row < M; row += nw) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     const size_t ro = (size_t)row * D;
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           *reinterpret_cast<float4*>(dx32 + ro + c) = o;
         }
         if (dx16) *reinterpret_cast<uint2*>(dx16 + ro + c) = uint2{pack_bf2(o.x, o.y), pack_bf2(o.z, o.w)};
+        if (want_colsum) { ao[i].x += round_bf(o.x); ao[i].y += round_bf(o.y); ao[i].z += round_bf(o.z); ao[i].w += round_bf(o.w); }
       }
     }
   }
@@ -165,30 +169,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
-      *reinterpret_cast<float4*>(red + (wave * 2 + 0) * D + c) = ag[i];
-      *reinterpret_cast<float4*>(red + (wave * 2 + 1) * D + c) = ab[i];
+      *reinterpret_cast<float4*>(red + (wave * NP + 0) * D + c) = ag[i];
+      *reinterpret_cast<float4*>(red + (wave * NP + 1) * D + c) = ab[i];
+      if (want_colsum) *reinterpret_cast<float4*>(red + (wave * NP + 2) * D + c) = ao[i];
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+  for (int idx = threadIdx.x; idx < NP * D; idx += 256) {
     const int which = idx / D, c = idx - which * D;
-    const float v = (red[(0 * 2 + which) * D + c] + red[(1 * 2 + which) * D + c]) +
-                    (red[(2 * 2 + which) * D + c] + red[(3 * 2 + which) * D + c]);
-    ws[(size_t)blockIdx.x * 2 * D + idx] = v;
+    const float v = (red[(0 * NP + which) * D + c] + red[(1 * NP + which) * D + c]) +
+                    (red[(2 * NP + which) * D + c] + red[(3 * NP + which) * D + c]);
+    ws[(size_t)blockIdx.x * NP * D + idx] = v;
   }
 }
 
 // sum of the per-block partials: 16 columns per workgroup x 16 groups of partial blocks (128+ workgroups for D = 1024
 // instead of 32), four independent accumulators per thread so the strided loads overlap, fixed-order LDS combine
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int acc) {
+                                                     float* __restrict__ dbeta, int acc, float* __restrict__ dcol, int NP) {
   __shared__ float red[16][16];
   const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + c;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (idx < 2 * D) {
+  if (idx < NP * D) {
     const float* p = ws + idx;
-    const size_t st = (size_t)2 * D;
+    const size_t st = (size_t)NP * D;
     int b = rg;
     for (; b + 48 < nblk; b += 64) {
       s0 += p[(size_t)b * st]; s1 += p[(size_t)(b + 16) * st]; s2 += p[(size_t)(b + 32) * st]; s3 += p[(size_t)(b + 48) * st];
@@ -197,13 +202,14 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ w
   }
   red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg != 0 || idx >= 2 * D) return;
+  if (rg != 0 || idx >= NP * D) return;
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) s += red[r][c];
-  float* base = idx < D ? dgamma : dbeta;
+  const int which = idx / D;
+  float* base = which == 0 ? dgamma : (which == 1 ? dbeta : dcol);
   if (!base) return;
-  float* dst = base + (idx < D ? idx : idx - D);
+  float* dst = base + (idx - which * D);
   *dst = acc ? *dst + s : s;
 }
 
@@ -421,21 +427,22 @@ extern "C" int crl_layernorm_fwd(const float* x, const float* gamma, const float
   return 0;
 }
 
-extern "C" size_t crl_layernorm_bwd_ws_bytes(int64_t D) { return (size_t)LNB_MAXBLK * 2 * D * sizeof(float); }
+extern "C" size_t crl_layernorm_bwd_ws_bytes(int64_t D) { return (size_t)LNB_MAXBLK * 3 * D * sizeof(float); }
 
 extern "C" int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, int64_t M, int64_t D, float* dx_f32,
-                                 int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int acc_wgrad,
+                                 int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int acc_wgrad,
                                  void* ws, void* stream) {
   CRL_CHECK(M > 0 && D > 0 && (D % 4) == 0 && D <= LN_MAXV * 256, "crl_layernorm_bwd: bad shape %lld x %lld (D %% 4, D <= 2048)", (long long)M, (long long)D);
   CRL_CHECK((dy_f32 || dy_bf16) && x && gamma && mean && rstd && ws && (dx_f32 || dx_bf16), "crl_layernorm_bwd: null pointer");
   const int nblk = (int)(blocks_for(M, 4) < (unsigned)LNB_MAXBLK ? blocks_for(M, 4) : LNB_MAXBLK);
   hipStream_t s = as_stream(stream);
-  ln_bwd_kernel<<<nblk, 256, 4 * 2 * D * sizeof(float), s>>>(dy_f32, (const u16*)dy_bf16, x, gamma, mean, rstd, (int)M, (int)D,
-                                                             dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws);
+  const int np = dx_colsum ? 3 : 2;
+  ln_bwd_kernel<<<nblk, 256, 4 * np * D * sizeof(float), s>>>(dy_f32, (const u16*)dy_bf16, x, gamma, mean, rstd, (int)M, (int)D,
+                                                              dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws, dx_colsum ? 1 : 0);
   CRL_LAUNCH_CHECK("crl_layernorm_bwd");
-  if (dgamma || dbeta) {
-    ln_bwd_reduce<<<blocks_for(2 * D, 16), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad);
+  if (dgamma || dbeta || dx_colsum) {
+    ln_bwd_reduce<<<blocks_for(np * D, 16), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad, dx_colsum, np);
     CRL_LAUNCH_CHECK("crl_layernorm_bwd(reduce)");
   }
   return 0;

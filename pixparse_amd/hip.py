@@ -31,7 +31,7 @@ SIGNATURES = {
     'crl_colsum_bf16': (I, [P, L, L, L, P, I, P, P]),
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),
     'crl_layernorm_bwd_ws_bytes': (Z, [L]),
-    'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, I, P, P]),
+    'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, P, I, P, P]),
     'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, P]),
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
                          I, I, I, I, F, I, P]),

@@ -70,11 +70,13 @@ class _Base:
         ops.layernorm_fwd(x, self.P(name + '.weight'), self.P(name + '.bias'), eps, y32, y16, mean, rstd)
         return y32, y16
 
-    def ln_bwd(self, name, key, x, dy_f32, dy_bf16, dx_f32, acc, dx_bf16):
-        M = x.shape[0]
+    def ln_bwd(self, name, key, x, dy_f32, dy_bf16, dx_f32, acc, dx_bf16, bias_of=None):
+        """bias_of: name of the Linear whose OUTPUT gradient dx_bf16 is -- its bias gradient (column sums of dx_bf16) is
+        accumulated by the same kernel instead of a separate colsum pass (lin_wgrad is then called with has_bias=False)"""
         ops.layernorm_bwd(dy_f32, dy_bf16, x, self.P(name + '.weight'), self.bufs.t[self.tag + '.' + key + '.mean'],
                           self.bufs.t[self.tag + '.' + key + '.rstd'], dx_f32, acc, dx_bf16,
-                          self.G(name + '.weight'), self.G(name + '.bias'), True)
+                          self.G(name + '.weight'), self.G(name + '.bias'), True,
+                          dx_colsum=self.G(bias_of + '.bias') if bias_of else None)
 
     # Linear backward: wgrad + bias grad (dgrad is issued by the caller: its epilogue differs)
     def lin_wgrad(self, name, dy, x, has_bias=True, n=None, k=None):
@@ -184,7 +186,8 @@ class ViTEngine(_Base):
         tg = self.tag + '.'
         dx = self.buf('dx', (M, D), F32)
         gb = self.buf('gb', (M, D), BF16)
-        self.ln_bwd('norm', 'norm', self.x_last, denc, None, dx, False, gb)
+        last = a['depth'] - 1
+        self.ln_bwd('norm', 'norm', self.x_last, denc, None, dx, False, gb, bias_of=f'blocks.{last}.mlp.fc2')
         if on_layer_done:
             on_layer_done(self.prefix + 'norm.weight')
         scale = (D // self.heads) ** -0.5
@@ -200,20 +203,22 @@ class ViTEngine(_Base):
             qkv, o, lse = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.lse']
             pre, act = T[tg + k + '.pre'], T[tg + k + '.act']
             # ---- MLP: x3 = x2 + fc2(gelu(fc1(LN2(x2))));  gb = bf16(dx3)
+            # (the bias gradients of fc2 / attn.proj = column sums of gb were accumulated by the LayerNorm backward that wrote gb)
             ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
-            self.lin_wgrad(bp + 'mlp.fc2', gb, act)
+            self.lin_wgrad(bp + 'mlp.fc2', gb, act, has_bias=False)
             ops.linear_dgrad(dpre, self.W(bp + 'mlp.fc1.weight'), dh)
             self.lin_wgrad(bp + 'mlp.fc1', dpre, h2)
-            self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb)     # dx := dx2, gb := bf16(dx2)
+            self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb, bias_of=bp + 'attn.proj')     # dx := dx2, gb := bf16(dx2)
             # ---- attention: x2 = xin + proj(attn(qkv(LN1(xin))))
             ops.linear_dgrad(gb, self.W(bp + 'attn.proj.weight'), do)
-            self.lin_wgrad(bp + 'attn.proj', gb, o)
+            self.lin_wgrad(bp + 'attn.proj', gb, o, has_bias=False)
             q3, dq3 = qkv.view(B, N, 3 * D), dqkv.view(B, N, 3 * D)
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do.view(B, N, D), lse, delta,
                          dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], self.heads, scale, False)
             ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
             self.lin_wgrad(bp + 'attn.qkv', dqkv, h1)
-            self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb)    # dx := d(xin)
+            self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb,    # dx := d(xin) = d(x3 of block i-1)
+                        bias_of=f'blocks.{i - 1}.mlp.fc2' if i > 0 else None)
             if on_layer_done:
                 on_layer_done(self.prefix + bp + 'norm1.weight')
         if a['pre_norm']:
@@ -581,15 +586,15 @@ class BartEngine(_Base):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             g = lambda n: Tb[tg + k + n]
             # ---- h_out = LN3(t3), t3 = h2 + fc2(gelu(fc1(h2b)))
-            self.ln_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, False, dtb)
+            self.ln_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, False, dtb, bias_of=lp + 'fc2')
             ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.pre'))
-            self.lin_wgrad(lp + 'fc2', dtb, g('.act'))
+            self.lin_wgrad(lp + 'fc2', dtb, g('.act'), has_bias=False)
             ops.linear_dgrad(dpre, self.W(lp + 'fc1.weight'), dhb)
             self.lin_wgrad(lp + 'fc1', dpre, g('.ln2.y16'))
             # ---- h2 = LN2(t2), t2 = h1 + out_c(attn(q_c(h1b), kv_c(enc)))
-            self.ln_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, False, dtb)
+            self.ln_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, False, dtb, bias_of=lp + 'encoder_attn.out_proj')
             ops.linear_dgrad(dtb, self.W(lp + 'encoder_attn.out_proj.weight'), do)
-            self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'))
+            self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'), has_bias=False)
             kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
             ops.attn_bwd(g('.q2').view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], g('.o2').view(B, T, D), do.view(B, T, D), g('.lse2'), delta,
                          dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False)
@@ -599,9 +604,9 @@ class BartEngine(_Base):
             ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
             ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
-            self.ln_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, False, dtb)
+            self.ln_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, False, dtb, bias_of=lp + 'self_attn.out_proj')
             ops.linear_dgrad(dtb, self.W(lp + 'self_attn.out_proj.weight'), do)
-            self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'))
+            self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'), has_bias=False)
             q3, dq3 = g('.qkv').view(B, T, 3 * D), dqkv.view(B, T, 3 * D)
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
                          dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True)

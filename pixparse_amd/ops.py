@@ -116,11 +116,13 @@ def layernorm_fwd(x, gamma, beta, eps, y_f32, y_bf16, mean, rstd) -> None:
 
 
 def layernorm_bwd(dy_f32, dy_bf16, x, gamma, mean, rstd, dx_f32, dx_accumulate, dx_bf16, dgamma, dbeta,
-                  acc_wgrad: bool = True) -> None:
+                  acc_wgrad: bool = True, dx_colsum: Optional[torch.Tensor] = None) -> None:
+    """dx_colsum [D] (+)= column sums of the bf16 gradient written to dx_bf16 (the bias gradient of the Linear it feeds)"""
     M, D = x.shape
+    assert dx_colsum is None or dx_bf16 is not None
     ws = _scratch.get(hip.query('crl_layernorm_bwd_ws_bytes', D), x.device)
     hip.call('crl_layernorm_bwd', _p(dy_f32), _p(dy_bf16), _p(x), _p(gamma), _p(mean), _p(rstd), M, D, _p(dx_f32),
-             int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), int(acc_wgrad), _p(ws), _stream())
+             int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(dx_colsum), int(acc_wgrad), _p(ws), _stream())
 
 
 HEAD_DIM = 64   # the attention kernels index head h at channel h * 64

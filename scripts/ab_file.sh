@@ -9,7 +9,7 @@ EXTRA=""; [ "$F" = attention.hip ] && EXTRA="-fno-slp-vectorize"
 for v in head tree head tree; do
   if [ $v = head ]; then cp $C/$F.head $C/_ab_$F; else cp $C/$F $C/_ab_$F; fi
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA -c $C/_ab_$F -o $OBJ || exit 1
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $C/gemm.o $C/gemm256.o $C/attention.o $C/rowops.o $C/loss_optim.o $C/swin.o $C/preprocess.o $C/skinny.o $C/attn_decode.o $C/capi.o || exit 1
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $(ls $C/*.o | tr "\n" " ") || exit 1
   echo "== $v: $(python bench.py --no-cpu-baseline --no-roofline --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "docs/s", d["ms_per_step"], "ms/step")')"
 done
 rm -f $C/_ab_$F

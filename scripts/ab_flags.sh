@@ -7,6 +7,6 @@ OBJ=$C/${F%.*}.o
 EXTRA=""; [ "$F" = attention.hip ] && EXTRA="-fno-slp-vectorize"
 for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA $flags -c $C/$F -o $OBJ || exit 1
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $C/gemm.o $C/gemm256.o $C/attention.o $C/rowops.o $C/loss_optim.o $C/swin.o $C/preprocess.o $C/skinny.o $C/attn_decode.o $C/capi.o || exit 1
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $(ls $C/*.o | tr "\n" " ") || exit 1
   echo "== $flags: $(python bench.py --no-cpu-baseline --no-roofline --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "docs/s", d["ms_per_step"], "ms/step")')"
 done

@@ -37,6 +37,22 @@ def gemm_case(name, layout, M, N, K, epi=ops.EPI_BF16, policy=0):
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
+    if which == 'gemm2x':   # automatic plan (256x256 one-per-CU + remainder) vs the 256x128 two-per-CU kernel, step shapes, interleaved
+        M = 49512
+        for rep in range(2):
+            for pol in (0, 3):
+                gemm_case('qkv', 'NT', M, 3072, 1024, policy=pol)
+                gemm_case('proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, policy=pol)
+                gemm_case('fc1 gelu', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU, policy=pol)
+                gemm_case('fc2 resid', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, policy=pol)
+                gemm_case('dec kv', 'NT', M, 2048, 1024, policy=pol)
+                gemm_case('dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, policy=pol)
+                gemm_case('dgrad fc1', 'NN', M, 4096, 1024, policy=pol)
+                gemm_case('dgrad qkv', 'NN', M, 3072, 1024, policy=pol)
+                gemm_case('dgrad proj', 'NN', M, 1024, 1024, policy=pol)
+                gemm_case('lm head', 'NT', 8184, 50304, 1024, policy=pol)
+                gemm_case('square 8192', 'NT', 8192, 8192, 8192, policy=pol)
+        sys.exit(0)
     if which == 'gemm':
         for pol in (2, 1):
             gemm_case('square 8192', 'NT', 8192, 8192, 8192, policy=pol)

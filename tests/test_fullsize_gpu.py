@@ -77,9 +77,20 @@ def test_attention_full_sequence_sampled_rows_and_identities(dev):
     assert float((a - b).abs().max()) < 2e-2 * float(b.abs().max()) + 0.5, float((a - b).abs().max())
 
 
+@pytest.mark.parametrize('policy', [0, 2, 3])
 @pytest.mark.parametrize('N,K,epi', [(4096, 1024, 'gelu'), (1024, 4096, 'resid'), (3072, 1024, 'plain')])
-def test_gemm_full_rows_sampled(dev, N, K, epi):
-    """the step's encoder GEMMs at all 49512 token rows (256-tile kernel + wave-quantisation remainder): sampled rows"""
+def test_gemm_full_rows_sampled(dev, N, K, epi, policy):
+    """the step's encoder GEMMs at all 49512 token rows: the automatic plan, the 256x256 kernel alone and the 256x128
+    two-per-CU kernel alone; sampled rows (first / last tile rows included)"""
+    from pixparse_amd import hip, ops
+    hip.call('crl_gemm_set_policy', policy)
+    try:
+        _gemm_full_rows(dev, N, K, epi)
+    finally:
+        hip.call('crl_gemm_set_policy', 0)
+
+
+def _gemm_full_rows(dev, N, K, epi):
     from pixparse_amd import ops
     M = ROWS
     x = _rnd((M, K), dev, 1.0, 1, BF16)

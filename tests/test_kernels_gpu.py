@@ -145,20 +145,24 @@ def test_gemm_strided_views_and_errors(dev):
         ops.linear_fwd(rnd((8, 40), dev, 1, 1, BF16), rnd((8, 40), dev, 1, 2, BF16), None, torch.empty(8, 8, dtype=BF16, device=dev))  # K % 32
 
 
+@pytest.mark.parametrize('policy', [2, 3])
 @pytest.mark.parametrize('K', [64, 128, 192, 448])
-def test_gemm_256_kernel_all_layouts(dev, K):
-    """the 256x256 8-phase kernel forced on ragged shapes (odd / even / single K-tile counts), against the 128 kernel's
-    reference math; then the split-K wgrad path through fp32 slabs"""
+def test_gemm_256_kernel_all_layouts(dev, K, policy):
+    """the 256x256 8-phase kernel (policy 2) and the 256x128 two-workgroups-per-CU kernel (policy 3: NT / NN, the wgrad
+    layout stays on the 256x256 kernel) forced on ragged shapes (odd / even / single K-tile counts, ragged M and N tiles),
+    against fp32 torch; then the split-K wgrad path through fp32 slabs"""
     from pixparse_amd import hip, ops
     M, N = 600, 520
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
     dy = rnd((M, N), dev, 1.0, 4, BF16)
-    hip.call('crl_gemm_set_policy', 2)
+    hip.call('crl_gemm_set_policy', policy)
     try:
         out = torch.empty(M, N, dtype=BF16, device=dev)
         pre = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out)
+        close(out, x.float() @ w.float().t() + bias.to(BF16).float(), 1e-2, 1e-2, '256 NT bf16')
         ops.linear_fwd(x, w, bias, out, ops.EPI_BF16_GELU, aux=pre)
         ref = x.float() @ w.float().t() + bias.to(BF16).float()
         close(pre, ref, 1e-2, 1e-2, '256 NT aux')
@@ -172,6 +176,15 @@ def test_gemm_256_kernel_all_layouts(dev, K):
             dx = torch.empty(M, K, dtype=BF16, device=dev)
             ops.linear_dgrad(dyc, wc, dx)
             close(dx, dyc.float() @ wc.float(), 1e-2, 2e-2, '256 NN')
+            h = rnd((M, K), dev, 1.0, 6, BF16)
+            hf = h.float().requires_grad_(True)
+            torch.nn.functional.gelu(hf).backward((dyc.float() @ wc.float()).to(BF16).float())
+            ops.linear_dgrad(dyc, wc, dx, ops.EPI_BF16_DGELU, aux=h)
+            close(dx, hf.grad, 1e-2, 2e-2, '256 NN + dGELU')
+            accb = rnd((M, K), dev, 1.0, 7)
+            wantb = accb + dyc.float() @ wc.float()
+            ops.linear_dgrad(dyc, wc, accb, ops.EPI_F32_ACC)
+            close(accb, wantb, 1e-3, 2e-2, '256 NN F32_ACC')
         dw = torch.full((N, K), 3.0, device=dev)
         ops.linear_wgrad(dy, x, dw, accumulate=True)
         close(dw, 3.0 + dy.float().t() @ x.float(), 2e-3, 5e-2, '256 TN acc')
@@ -245,11 +258,17 @@ def test_layernorm(dev, M, D):
     dx = base.clone()
     dxb = torch.empty(M, D, dtype=BF16, device=dev)
     dg, db = torch.ones(D, device=dev), torch.ones(D, device=dev)
-    ops.layernorm_bwd(dy32, dy16, x, gamma, mean, rstd, dx, True, dxb, dg, db, True)
+    dcol = torch.full((D,), 2.0, device=dev)
+    ops.layernorm_bwd(dy32, dy16, x, gamma, mean, rstd, dx, True, dxb, dg, db, True, dx_colsum=dcol)
     close(dx, base + xr.grad, 1e-4, 1e-4, 'ln bwd dx (accumulated)')
     close(dxb, base + xr.grad, 1e-2, 1e-2, 'ln bwd dx bf16 = bf16(final)')
     close(dg, 1 + gr.grad, 1e-4, 1e-3, 'ln dgamma (+=)')
     close(db, 1 + br.grad, 1e-4, 1e-3, 'ln dbeta (+=)')
+    # fused bias gradient of the Linear that produced x's branch: column sums of the bf16 tensor just written (+=)
+    close(dcol, 2.0 + dxb.float().sum(0), 1e-5, 1e-3, 'ln bwd fused column sums of dx_bf16')
+    dx_b, dxb_b, dg_b, db_b = base.clone(), torch.empty_like(dxb), torch.ones(D, device=dev), torch.ones(D, device=dev)
+    ops.layernorm_bwd(dy32, dy16, x, gamma, mean, rstd, dx_b, True, dxb_b, dg_b, db_b, True)     # without: identical outputs
+    assert torch.equal(dx, dx_b) and torch.equal(dxb, dxb_b) and torch.equal(dg, dg_b) and torch.equal(db, db_b)
     # in-place: dy_f32 aliases dx_f32, no accumulate
     d2 = dy32.clone()
     ops.layernorm_bwd(d2, None, x, gamma, mean, rstd, d2, False, None, None, None, True)
@@ -545,10 +564,10 @@ def test_adamw_with_device_gradscaler_vs_torch(dev):
     want_scales = [1024.0, 512.0, 512.0, 1024.0, 1024.0, 2048.0]      # after each update()
     for i, g in enumerate(grads):
         s_dev = float(opt.state[4])
-        assert s_dev == float(tsc.get_scale()), (i, s_dev, tsc.get_scale())
+        assert s_dev == ([1024.0] + want_scales)[i], (i, s_dev)
         arena.g.copy_(g * s_dev)                       # what backward leaves: gradients of the scaled loss
         opt.step(clip_norm=1.0, zero_grad=True, scaler=sc, grad_divisor=1.0)
-        pr.grad = g * tsc.get_scale()
+        pr.grad = g * float(tsc.scale(torch.ones((), device=dev)))     # scaler.scale(loss) initialises / applies the scale
         tsc.unscale_(topt)
         torch.nn.utils.clip_grad_norm_([pr], 1.0)
         tsc.step(topt)
