@@ -2,11 +2,15 @@
 `--train.*`, `--task.*`, `--task.opt.*`, `--data.train.*` flags (dash or underscore spelling, like simple_parsing's
 DASH variants), DeviceEnv, TaskFactory.create_task, per-interval loop, `checkpoint-{i}.pt` = model.state_dict().
 
-Only the synthetic loader is built in (real-data IO via chug / webdataset is the f-1 "next" row of SURVEY §8):
+Data: `--data.train.source` (tar shards / directories of page images + .json annotations, ref app/train.py:171-181 ->
+data/loader.py) goes through data.create_loader with the task's image / annotation preprocessing; `--data.train.gpu-preprocess
+true` moves the resize + normalise onto the GPU.  Without a source a synthetic loader of the same shapes is used:
 
     python -m pixparse_amd.app.train --task.model-name cruller_large_1280x960 --task.dtype bfloat16 \
         --task.opt.learning-rate 3e-4 --task.opt.clip-grad-value 1.0 --task.opt.clip-grad-mode norm \
         --data.train.batch-size 8 --data.train.num-batches 20 --train.num-intervals 2 --train.output-dir /tmp/out
+    python -m pixparse_amd.app.train ... --data.train.source '/data/shards/docs-{000..127}.tar' --data.train.num-samples 100000 \
+        --data.train.batch-size 8 --data.train.num-workers 8 --data.train.gpu-preprocess true
 """
 import argparse
 import dataclasses
@@ -44,9 +48,16 @@ class TrainCfg:
 
 @dataclass
 class SyntheticDataCfg:
+    """--data.train.*: DatasetCfg fields (ref data/config.py:12-20) when `source` is given, else the synthetic loader's"""
     batch_size: int = 8
-    num_batches: int = 10     # batches per interval
+    num_batches: int = 10     # synthetic: batches per interval
     ragged: bool = False
+    source: Optional[str] = None
+    num_samples: Optional[int] = None
+    split: str = 'train'
+    format: str = 'webdataset'
+    num_workers: int = 4
+    gpu_preprocess: bool = False
 
 
 def _add_flags(parser, prefix, cls):
@@ -140,9 +151,22 @@ def main(argv=None):
         sd = sd.get('model', sd)
         task.model.load_state_dict({k[7:] if k.startswith('module.') else k: v for k, v in sd.items()})   # ref app/eval.py:135
     m = task.model
-    loader = SyntheticLoaderBundle(batch_size=data_cfg.batch_size, num_batches=data_cfg.num_batches, in_chans=m.in_chans,
-                                   img_size=m.img_size, max_length=m.max_length, vocab_size=task.vocab_size, seed=train_cfg.seed,
-                                   rank=device_env.global_rank, ragged=data_cfg.ragged)
+    if data_cfg.source:
+        # ref app/train.py:171-181: the task supplies the preprocessing, the loader the IO
+        from ..data import DatasetCfg, DeviceImagePreprocess, create_loader
+        assert data_cfg.num_samples, '--data.train.num-samples (samples per interval, all ranks) is required with a source'
+        ds_cfg = DatasetCfg(source=data_cfg.source, num_samples=data_cfg.num_samples, batch_size=data_cfg.batch_size, split=data_cfg.split,
+                            format=data_cfg.format, num_workers=data_cfg.num_workers, gpu_preprocess=data_cfg.gpu_preprocess)
+        image_preprocess = task.image_preprocess_train
+        if ds_cfg.gpu_preprocess:
+            image_preprocess = DeviceImagePreprocess(m.img_size, task.img_mean, task.img_std, task.num_image_chs, device_env.device)
+        loader = create_loader(ds_cfg, is_train=True, collate_fn=getattr(task, 'collate_fn', None), image_preprocess=image_preprocess,
+                               anno_preprocess=task.anno_preprocess_train, image_fmt=task_cfg.model.image_encoder.image_fmt,
+                               seed=train_cfg.seed, world_size=device_env.world_size, global_rank=device_env.global_rank)
+    else:
+        loader = SyntheticLoaderBundle(batch_size=data_cfg.batch_size, num_batches=data_cfg.num_batches, in_chans=m.in_chans,
+                                       img_size=m.img_size, max_length=m.max_length, vocab_size=task.vocab_size, seed=train_cfg.seed,
+                                       rank=device_env.global_rank, ragged=data_cfg.ragged)
     task.train_setup(num_batches_per_interval=loader.num_batches)
     if device_env.is_primary():
         _logger.info(task)
