@@ -179,11 +179,13 @@ int crl_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float*
 /* generation: one token per sequence at position *step_dev (device int) -> f32 [B, D] */
 int crl_embed_decode(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int D, int pos_offset,
                      int vocab, const int* step_dev, void* stream);
-/* dtok[ids] += dt (fp32 atomics: the order of the adds to a row that occurs several times is not fixed, so this
- * gradient is reproducible only to fp32 rounding; dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt.
+/* dtok[ids] += dt (dtok is the tied LM-head grad), dpos[t+off] (+)= sum_b dt.  Deterministic: the rows of a token that
+ * occurs several times are added in the order of their positions (counting rank + segmented sums in ws, no float
+ * atomics), so the result does not depend on scheduling.  ws >= crl_embed_bwd_ws_bytes(B, T, D), 16-byte aligned.
  * ids outside [0, vocab) (torch: device assert): forward rows become NaN, backward skips them -- never out of bounds. */
+size_t crl_embed_bwd_ws_bytes(int B, int T, int D);
 int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos,
-                  int B, int T, int D, int pos_offset, int vocab, void* stream);
+                  int B, int T, int D, int pos_offset, int vocab, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- shifted-token cross-entropy
  * ref: task/task_cruller_pretrain.py:118,251-256  nn.CrossEntropyLoss(ignore_index=-100) on bf16

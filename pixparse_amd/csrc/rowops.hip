@@ -2,8 +2,8 @@
 // statistics, no LDS in the forward), bias-gradient column sums, decoder embedding, ViT token
 // assembly, im2row for the patch conv, Swin patch-merge permutation, casts.  All accesses are
 // 8/16 bytes per lane and row-contiguous (guide G13); reductions over rows are two-stage and
-// deterministic (per-block partials in a caller-provided workspace, no float atomics) except the
-// token-embedding scatter, which has no fixed destination order and uses fp32 atomics.
+// deterministic (per-block partials in a caller-provided workspace, no float atomics), the
+// token-embedding scatter included (counting rank + segmented sums).
 #include "common.h"
 
 namespace {
@@ -278,15 +278,88 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     *reinterpret_cast<float4*>(out + (size_t)row * D + c) = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
   }
 }
-__global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dt,
-                                                            float* __restrict__ dtok, int BT, int D, int vocab) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= BT) return;
-  const int64_t id = ids[row];
-  if (id < 0 || id >= vocab) return;   // never scatter outside the embedding entry (its neighbours in the arena are other parameters' gradients)
-  float* dr = dtok + (size_t)id * D;
-  for (int c = lane; c < D; c += 64) atomicAdd(dr + c, dt[(size_t)row * D + c]);  // 256 contiguous bytes per wave-instruction
+// Token-embedding gradient: dtok[ids[r]] += dt[r] for every row r -- DETERMINISTIC, no float atomics (the fp32
+// atomic scatter made the tied embedding / LM-head gradient depend on the order in which duplicate tokens arrived: every
+// sequence starts with the same prompt token, so (g + a) + b vs (g + b) + a differed in the last bit from run to run).
+//   1. embed_rank_kernel: counting rank.  Row r gets its position in the stable sort of the ids,
+//        pos = #{j : ids[j] < ids[r]} + #{j < r : ids[j] == ids[r]},  plus its offset inside its run of equal ids and the
+//        run length (n^2 / 256 compares per workgroup over the L2-resident id list: microseconds for n = 8184).
+//   2. embed_seg_partial_kernel: the row at offset 0, 32, 64, ... of a run sums up to 32 rows of the run in sorted (=
+//        original) order -- independent loads, ordered adds.  Runs of <= 32 rows are added to dtok directly (one writer
+//        per id); longer runs (padding: thousands of rows) leave one partial row per chunk in the workspace.
+//   3. embed_seg_final_kernel: the first row of a long run adds its chunk partials in chunk order.
+// Bounded serial work per workgroup (32 rows), no dependence on arrival order, out-of-vocabulary ids skipped.
+constexpr int EMB_CHUNK = 32;
+__global__ __launch_bounds__(256) void embed_rank_kernel(const int64_t* __restrict__ ids, int n, int vocab, int* __restrict__ sorted_row,
+                                                         int* __restrict__ run_off, int* __restrict__ run_len, int* __restrict__ sorted_id) {
+  __shared__ int sh[3][4];
+  const int r = blockIdx.x;
+  const int64_t id = ids[r];
+  int less = 0, eq_before = 0, eq = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int64_t v = ids[j];
+    less += v < id;
+    eq += v == id;
+    eq_before += (v == id) && (j < r);
+  }
+  less = (int)wave_sum((float)less); eq = (int)wave_sum((float)eq); eq_before = (int)wave_sum((float)eq_before);   // counts < 2^24: exact in fp32
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][w] = less; sh[1][w] = eq; sh[2][w] = eq_before; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int L = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], E = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const int Eb = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    const int pos = L + Eb;
+    sorted_row[pos] = r;
+    run_off[pos] = Eb;
+    run_len[pos] = E;
+    sorted_id[pos] = (id >= 0 && id < vocab) ? (int)id : -1;
+  }
+}
+__global__ __launch_bounds__(256) void embed_seg_partial_kernel(const float* __restrict__ dt, float* __restrict__ dtok, int n, int D,
+                                                                const int* __restrict__ sorted_row, const int* __restrict__ run_off,
+                                                                const int* __restrict__ run_len, const int* __restrict__ sorted_id,
+                                                                float* __restrict__ partial) {
+  const int p = blockIdx.x;
+  const int off = run_off[p], len = run_len[p], id = sorted_id[p];
+  if (id < 0 || (off % EMB_CHUNK) != 0) return;
+  const int cnt = min(EMB_CHUNK, len - off);
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    float4 s{0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < cnt; q0 += 8) {          // 8 independent 16-byte loads in flight, added in order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = float4{0.f, 0.f, 0.f, 0.f};
+        if (q0 + u < cnt) v[u] = *reinterpret_cast<const float4*>(dt + (size_t)sorted_row[p + q0 + u] * D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    if (len <= EMB_CHUNK) {
+      float4* d = reinterpret_cast<float4*>(dtok + (size_t)id * D + c);
+      const float4 o = *d;
+      *d = float4{o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w};
+    } else {
+      *reinterpret_cast<float4*>(partial + (size_t)p * D + c) = s;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void embed_seg_final_kernel(float* __restrict__ dtok, int D, const int* __restrict__ run_off,
+                                                              const int* __restrict__ run_len, const int* __restrict__ sorted_id,
+                                                              const float* __restrict__ partial) {
+  const int p = blockIdx.x;
+  const int len = run_len[p], id = sorted_id[p];
+  if (id < 0 || run_off[p] != 0 || len <= EMB_CHUNK) return;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    float4* d = reinterpret_cast<float4*>(dtok + (size_t)id * D + c);
+    float4 s = *d;
+    for (int q = 0; q < len; q += EMB_CHUNK) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)(p + q) * D + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *d = s;
+  }
 }
 __global__ void embed_bwd_pos_kernel(const float* __restrict__ dt, float* __restrict__ dpos, int acc, int B, int T, int D, int off) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over T*D
@@ -475,12 +548,29 @@ extern "C" int crl_embed_decode(const int64_t* ids, const float* tok, const floa
   CRL_LAUNCH_CHECK("crl_embed_decode");
   return 0;
 }
+extern "C" size_t crl_embed_bwd_ws_bytes(int B, int T, int D) {
+  const size_t n = (size_t)B * T;
+  return ((4 * n * sizeof(int) + 255) / 256) * 256 + n * (size_t)D * sizeof(float);   // sort bookkeeping + one partial row per position
+}
+
 extern "C" int crl_embed_bwd(const int64_t* ids, const float* dt, float* dtok, float* dpos, int acc_pos, int B, int T, int D,
-                             int pos_offset, int vocab, void* stream) {
-  CRL_CHECK(B > 0 && T > 0 && D > 0 && vocab > 0, "crl_embed_bwd: bad shape");
+                             int pos_offset, int vocab, void* ws, size_t ws_bytes, void* stream) {
+  CRL_CHECK(B > 0 && T > 0 && D > 0 && (D % 4) == 0 && vocab > 0, "crl_embed_bwd: bad shape");
+  CRL_CHECK(ws && ws_bytes >= crl_embed_bwd_ws_bytes(B, T, D), "crl_embed_bwd: workspace too small (need %zu bytes)", crl_embed_bwd_ws_bytes(B, T, D));
+  CRL_CHECK(((uintptr_t)ws % 16) == 0 && ((uintptr_t)dt % 16) == 0 && ((uintptr_t)dtok % 16) == 0, "crl_embed_bwd: 16-byte alignment required");
   hipStream_t s = as_stream(stream);
-  embed_bwd_tok_kernel<<<blocks_for((size_t)B * T, 4), 256, 0, s>>>(ids, dt, dtok, B * T, D, vocab);
-  CRL_LAUNCH_CHECK("crl_embed_bwd(tok)");
+  const int n = B * T;
+  int* sorted_row = (int*)ws;
+  int* run_off = sorted_row + n;
+  int* run_len = run_off + n;
+  int* sorted_id = run_len + n;
+  float* partial = (float*)((char*)ws + ((4 * (size_t)n * sizeof(int) + 255) / 256) * 256);
+  embed_rank_kernel<<<n, 256, 0, s>>>(ids, n, vocab, sorted_row, run_off, run_len, sorted_id);
+  CRL_LAUNCH_CHECK("crl_embed_bwd(rank)");
+  embed_seg_partial_kernel<<<n, 256, 0, s>>>(dt, dtok, n, D, sorted_row, run_off, run_len, sorted_id, partial);
+  CRL_LAUNCH_CHECK("crl_embed_bwd(partial)");
+  embed_seg_final_kernel<<<n, 256, 0, s>>>(dtok, D, run_off, run_len, sorted_id, partial);
+  CRL_LAUNCH_CHECK("crl_embed_bwd(final)");
   embed_bwd_pos_kernel<<<blocks_for((size_t)T * D, 256), 256, 0, s>>>(dt, dpos, acc_pos, B, T, D, pos_offset);
   CRL_LAUNCH_CHECK("crl_embed_bwd(pos)");
   return 0;

@@ -47,7 +47,8 @@ SIGNATURES = {
     'crl_vit_tokens_bwd': (I, [P, P, P, P, I, I, I, I, P]),
     'crl_embed_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
     'crl_embed_decode': (I, [P, P, P, P, I, I, I, I, P, P]),
-    'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    'crl_embed_bwd_ws_bytes': (Z, [I, I, I]),
+    'crl_embed_bwd': (I, [P, P, P, P, I, I, I, I, I, I, P, Z, P]),
     'crl_cross_entropy': (I, [P, L, P, L, I, F, F, P, P, P, P, P, P]),
     'crl_grad_norm_ws_bytes': (Z, []),
     'crl_grad_norm': (I, [P, L, F, F, P, P, P]),

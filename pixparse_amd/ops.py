@@ -218,7 +218,10 @@ def embed_fwd(ids, tok, pos, out, pos_offset: int = 2) -> None:
 
 def embed_bwd(ids, dt, dtok, dpos, pos_offset: int = 2, accumulate: bool = True) -> None:
     B, T = ids.shape
-    hip.call('crl_embed_bwd', _p(ids), _p(dt), _p(dtok), _p(dpos), int(accumulate), B, T, dt.shape[1], pos_offset, dtok.shape[0], _stream())
+    nbytes = hip.query('crl_embed_bwd_ws_bytes', B, T, dt.shape[1])
+    ws = _scratch.get(nbytes, dt.device)
+    hip.call('crl_embed_bwd', _p(ids), _p(dt), _p(dtok), _p(dpos), int(accumulate), B, T, dt.shape[1], pos_offset, dtok.shape[0],
+             _p(ws), nbytes, _stream())
 
 
 def cross_entropy(logits, target, V: int, loss_mul: float, grad_mul: float, loss, n_valid, row_loss, dlogits,

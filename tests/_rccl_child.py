@@ -110,7 +110,10 @@ def check_task(env):
     la, pa = run(env)
     lb, pb = run(LocalEnv)
     assert la == lb, (la, lb)
-    assert torch.equal(pa, pb)
+    if not torch.equal(pa, pb):
+        d = (pa - pb).abs()
+        idx = torch.nonzero(d > 0).flatten()
+        raise AssertionError(f'{idx.numel()} of {pa.numel()} parameters differ, max |diff| {float(d.max()):.3e}, first at {idx[:8].tolist()}')
 
 
 def main():

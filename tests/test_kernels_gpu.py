@@ -296,6 +296,39 @@ def test_colsum_cast_add(dev):
     assert torch.equal(y, 1 + d.float())
 
 
+def test_embed_scatter_is_deterministic_and_ordered(dev):
+    """token-embedding gradient: duplicates (every sequence starts with the prompt token, padding occurs thousands of times)
+    are added in position order on top of what the buffer holds (the tied LM-head gradient) -- bit-identical from run to
+    run and equal to a sequential fp32 loop; runs longer than the 32-row chunk go through the partial-sum path"""
+    from pixparse_amd import ops
+    B, T, D, V = 4, 300, 128, 1000
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, V, (B, T), generator=g)
+    ids[:, 0] = V - 1                                    # the prompt token of every sequence
+    ids[:, 200:] = 1                                     # 400 padding rows: a run far longer than one chunk
+    ids[1, 5:45] = 7                                     # a run of 40: two chunks
+    ids = ids.to(dev)
+    dt = rnd((B * T, D), dev, 1.0, 1)
+    base = rnd((V, D), dev, 1.0, 2)                      # non-zero destination: (g + a) + b must not become (g + b) + a
+    outs = []
+    for _ in range(3):
+        dtok, dpos = base.clone(), torch.zeros(T + 2, D, device=dev)
+        ops.embed_bwd(ids, dt, dtok, dpos)
+        outs.append(dtok)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    flat = ids.view(-1).cpu()
+    ref64 = base.double().cpu().index_add_(0, flat, dt.double().cpu())
+    close(outs[0], ref64.float().to(dev), 1e-5, 1e-4, 'embed scatter vs fp64 index_add')
+    # exact order for short runs: the prompt token's row = base + (((dt[0] + dt[T]) + dt[2T]) + dt[3T]) in fp32, position order
+    run = torch.zeros(D, device=dev)
+    for b in range(B):
+        run = run + dt[b * T]
+    assert torch.equal(outs[0][V - 1], base[V - 1] + run)
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[flat] = False
+    assert torch.equal(outs[0][untouched.to(dev)], base[untouched.to(dev)])
+
+
 def test_embed_tokens_im2row_merge(dev):
     from pixparse_amd import ops
     B, T, D, V = 3, 17, 64, 99

@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from test_loader_cpu import _make_docs, _task_fns, _write_tar
+from .test_loader_cpu import _make_docs, _task_fns, _write_tar
 
 pytestmark = pytest.mark.gpu
 
