@@ -69,6 +69,38 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return __builtin_fmaf(x * 0.39894228040143268f, g, 0.5f * (1.0f + e));
 }
 
+// Two elements at a time on the packed-fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): the GEMM epilogues run 128 of
+// these per lane with the matrix pipe idle, and the s_memtime timeline of the persistent kernel shows the GELU / dGELU epilogues
+// bound by VALU issue (about 124 clocks per element in the scalar form: ~21 simple ops + rcp + exp2).  Same formulas as above
+// (the two constants of z and of the rcp argument are folded into one).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void erf_parts2(f32x2 x, f32x2& erf_v, f32x2& gauss) {
+  f32x2 ax; ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+  const f32x2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  f32x2 t; t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  const f32x2 ge = (x * x) * -0.72134752044448170f;
+  gauss.x = __builtin_amdgcn_exp2f(ge.x); gauss.y = __builtin_amdgcn_exp2f(ge.y);
+  f32x2 p = t * 1.061405429f + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const f32x2 e = 1.0f - (p * t) * gauss;
+  erf_v.x = copysignf(e.x, x.x); erf_v.y = copysignf(e.y, x.y);
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  f32x2 e, g;
+  erf_parts2(x, e, g);
+  return (x * 0.5f) * (e + 1.0f);
+}
+__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
+  f32x2 e, g;
+  erf_parts2(x, e, g);
+  return (x * 0.39894228040143268f) * g + (e + 1.0f) * 0.5f;
+}
+// bf16 pair <-> two floats: one v_cvt_pk_bf16_f32 / one shift + one mask
+__device__ __forceinline__ uint32_t pack_bf2v(f32x2 v) { return pack_bf2(v.x, v.y); }
+__device__ __forceinline__ f32x2 unpack_bf2(uint32_t w) { f32x2 r; r.x = __uint_as_float(w << 16); r.y = __uint_as_float(w & 0xffff0000u); return r; }
+
 // ---- wave64 reductions ----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

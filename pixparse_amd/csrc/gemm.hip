@@ -253,6 +253,13 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   // DMA offsets are 32-bit and tiles may overhang by up to 127 rows
   CRL_CHECK((uint64_t)(a_rows + 128) * lda * 2 < (1ull << 32) && (uint64_t)(b_rows + 128) * ldb * 2 < (1ull << 32),
             "crl_gemm_bf16: operand larger than 4 GiB");
+  {
+    // the epilogue addresses C / aux / resid with 32-bit byte offsets through bounds-checked buffer descriptors (gemm_epilogue.h)
+    const uint64_t esz = epilogue >= CRL_EPI_F32_RESID ? 4 : 2;
+    CRL_CHECK((uint64_t)(M + 256) * (uint64_t)ldc * esz < (1ull << 32), "crl_gemm_bf16: output larger than 4 GiB");
+    if (aux) CRL_CHECK((uint64_t)(M + 256) * (uint64_t)ldaux * 2 < (1ull << 32), "crl_gemm_bf16: aux larger than 4 GiB");
+    if (resid) CRL_CHECK((uint64_t)(M + 256) * (uint64_t)ldr * 4 < (1ull << 32), "crl_gemm_bf16: resid larger than 4 GiB");
+  }
   GemmArgs a;
   a.A = (const u16*)A; a.B = (const u16*)B; a.bias = bias; a.C = C; a.aux = aux; a.resid = resid;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;

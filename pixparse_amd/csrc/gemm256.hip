@@ -30,6 +30,15 @@ using namespace gemmc;
 constexpr int T256 = 512;
 #define BAR() asm volatile("s_barrier" ::: "memory")
 
+// -DG_TIMING=<workgroup>: wave 0 of that workgroup records s_memtime at six points of every tile iteration (debug builds only:
+// scripts/gemm_timeline.py reads them through crl_gemm_debug_read)
+#ifdef G_TIMING
+__device__ unsigned long long g_tm[16][8];
+#define TM(pt) do { if ((int)blockIdx.x == G_TIMING && wave == 0 && lane == 0 && tile_iter < 16) g_tm[tile_iter][pt] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TM(pt) do { } while (0)
+#endif
+
 template <int LAYOUT, int EPI>
 __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,10 +150,26 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+#ifndef G_CU_STAGGER
+#define G_CU_STAGGER 0
+#endif
+#ifndef G_CUS_KT
+#define G_CUS_KT 22      // s_sleep units (64 clocks) per K tile: about half of a K tile's 1.4 us
+#endif
+  // Every persistent workgroup walks equally long tiles, so all 256 CUs reach their epilogues TOGETHER: the chip alternates
+  // between an MFMA-bound phase with HBM idle and an HBM-bound phase (tile-sized epilogue traffic of every CU at once) with
+  // the matrix pipes idle.  Half of the workgroups therefore start half a tile period late, once; the two populations then
+  // run their epilogues under each other's K loops for the rest of the tile walk.
+  if (G_CU_STAGGER && G_PERSIST && gridDim.y == 1 && ntiles >= 2 * (int)gridDim.x && ((blockIdx.x >> 3) & 1)) {
+    constexpr int base = EPI == CRL_EPI_BF16 ? 190 : EPI == CRL_EPI_BF16_GELU ? 340 : EPI == CRL_EPI_BF16_DGELU ? 310 : 480;
+    const int n = nk_all * G_CUS_KT + base;
+    for (int i = 0; i < n; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
   // prologue: half-tiles 0..5 in flight, first K tile (0..3) landed
   issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
   issue(1, 0); issue(1, 1);
   bool first_tile = true;
+  int tile_iter = 0;
   for (;;) {   // output tiles of this workgroup (exactly one unless G_PERSIST)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -154,9 +179,11 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  TM(0);
   if (first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetched half-tiles AND the previous epilogue's stores
   BAR();
+  TM(1);
   // stagger (guide §5 template): the wr==1 waves run one barrier behind, so on every SIMD one wave is in its
   // MFMA cluster while its partner (the wave 4 slots away shares the SIMD) issues LDS reads and DMA.
 #ifndef G_STAGGER
@@ -203,8 +230,10 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     tile_phases(std::integral_constant<int, 0>{}, te + 1, te + 2);
     tile_phases(std::integral_constant<int, 1>{}, te + 2, te + 3);
   }
+  TM(2);
   if (G_STAGGER && wr == 0) BAR();
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
+  TM(3);
 
   // ---------------- epilogue: lane (li, lq) holds C[m = .. + li][n = .. + 4 lq + 0..3]
   // opaque copies: nothing of the epilogue's address arithmetic may be hoisted above the K loop (it would sit in
@@ -218,7 +247,10 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
     issue(1, 0); issue(1, 1);
   }
+  TM(4);
   epilogue_tile<EPI, 128>(g, acc, m0e, n0e, wr, wc, lane_e, (size_t)blockIdx.y * g.slab_stride);
+  TM(5);
+  ++tile_iter;
   if (!has_next) break;
   logical = next_logical;
   first_tile = false;
@@ -237,6 +269,9 @@ int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
   int grid_x = a.ntm * a.ntn;
 #if G_PERSIST
   if (nsplit == 1 && grid_x > 256) grid_x = 256;   // one resident workgroup per CU walks the tiles
+#endif
+#ifdef G_GRID_CAP
+  if (nsplit == 1 && grid_x > G_GRID_CAP) grid_x = G_GRID_CAP;   // debug: fewer CUs busy (is a phase chip-bound or CU-bound?)
 #endif
   gemm256_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T256, 131072, s>>>(a);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(256)");
@@ -258,6 +293,10 @@ int launch256_epi(const GemmArgs& a, int epi, int nsplit, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef G_TIMING
+extern "C" int crl_gemm_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm), sizeof(g_tm)); }
+#endif
 
 // called by crl_gemm_bf16 (gemm.hip) for shapes where the big tile pays
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {

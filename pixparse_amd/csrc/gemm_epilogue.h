@@ -19,6 +19,220 @@ __device__ __forceinline__ void swap_strips(uint32_t& x0, uint32_t& x1, uint32_t
   x0 = r0[0]; y0 = r0[1]; x1 = r1[0]; y1 = r1[1];
 }
 
+// ---- Branch-free epilogue over bounds-checked buffer accesses (the default path) -------------------------------------------
+// Every tile-sized access of the epilogue is a raw buffer load / store of 16 bytes per lane through a descriptor that ends
+// at the last valid element: rows >= M fall past num_records by themselves, ragged columns are steered there with one
+// v_cndmask per access, a missing bias is a zero-record descriptor.  Out-of-range loads return zeros and out-of-range
+// stores are dropped by the hardware, so the whole epilogue is ONE basic block: hipcc schedules the loads of several row
+// groups ahead of the arithmetic and waits with counted vmcnt.  (With `if (ok) store` predicates it cut the code into one
+// block per store and put `global_load; s_waitcnt vmcnt(0)` chains between them: 4 dependent round trips for the bias, 8 to
+// 32 for a residual / saved-activation tile -- 12 to 31 us per 256x256 tile against 22 us for the whole K = 1024 main loop.)
+// All offsets are 32-bit: crl_gemm_bf16 checks that (M + 255) rows of C / aux / resid stay below 4 GiB.
+typedef unsigned epi_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ epi_u4 epi_ld(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+__device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, uint32_t off, epi_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0); }
+
+#ifndef G_EPI_XPOSE
+#define G_EPI_XPOSE 1
+#endif
+// Lane transposition in front of every tile-sized access (G_EPI_XPOSE).  The MFMAs leave lane (li = lane & 15, lq = lane >> 4)
+// with 16 bytes of ROW li: the 16 lanes of a quarter-wave touch 16 different rows, so a 1-KiB wave access reaches the
+// texture-address unit as 64 separate 16-byte requests -- the s_memtime timeline of the persistent kernel (scripts/
+// gemm_timeline.py) shows the epilogues moving 8-13 bytes per clock and CU, unchanged with 32 or 256 CUs active, i.e. bound by
+// the CU's request rate, not by HBM.  Four ds_bpermute_b32 per 16 bytes (LDS crossbar only, no LDS storage) re-deal the data so
+// that lane d owns chunk (d & 3) of row (d >> 2): four neighbouring lanes then cover 64 contiguous bytes and the same access is
+// 16 requests.  Arithmetic stays in the MFMA ("math") layout; loads are issued in the access layout and dealt back.
+template <bool BF16>
+struct EpiLanes {
+  int ar, ac;            // access role: row within the 16-row group, 16-byte chunk within the row segment
+  int fwd, inv;          // ds_bpermute byte addresses: math -> access, access -> math
+  __device__ __forceinline__ explicit EpiLanes(int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    auto bitswap = [](int c) { return ((c & 1) << 1) | (c >> 1); };   // bf16: chunk c of a strip pair lives in lane group lq = bitswap(c) after swap_strips
+    if (G_EPI_XPOSE) {
+      ar = lane >> 2; ac = lane & 3;
+      fwd = 4 * (ar + 16 * (BF16 ? bitswap(ac) : ac));
+      inv = 4 * (4 * li + (BF16 ? bitswap(lq) : lq));
+    } else {
+      ar = li; ac = BF16 ? bitswap(lq) : lq;
+      fwd = inv = 4 * lane;
+    }
+  }
+  __device__ __forceinline__ epi_u4 to_access(epi_u4 v) const {
+    if (G_EPI_XPOSE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (unsigned)__builtin_amdgcn_ds_bpermute(fwd, (int)v[k]);
+    }
+    return v;
+  }
+  __device__ __forceinline__ epi_u4 to_math(epi_u4 v) const {
+    if (G_EPI_XPOSE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (unsigned)__builtin_amdgcn_ds_bpermute(inv, (int)v[k]);
+    }
+    return v;
+  }
+};
+
+template <int EPI, int QN>
+__device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc)[2][2][4][2], int m0e, int n0e, int wr, int wc, int lane_e,
+                                                  size_t slab_off) {
+  constexpr bool BIAS_EPI = (EPI == CRL_EPI_BF16 || EPI == CRL_EPI_BF16_GELU || EPI == CRL_EPI_F32_RESID);
+  constexpr bool BF16_OUT = (EPI == CRL_EPI_BF16 || EPI == CRL_EPI_BF16_GELU || EPI == CRL_EPI_BF16_DGELU);
+  constexpr uint32_t ES = BF16_OUT ? 2u : 4u;
+  const int lq = lane_e >> 4;
+  const EpiLanes<BF16_OUT> L(lane_e);
+  const uint32_t Mu = (uint32_t)g.M, Nu = (uint32_t)g.N;
+  const uint32_t nrecC = (uint32_t)(((size_t)(Mu - 1) * (uint32_t)g.ldc + Nu) * ES);
+  const __amdgpu_buffer_rsrc_t rC = epi_rsrc((const char*)g.C + slab_off * 4, nrecC);
+  const uint32_t mrow = (uint32_t)(m0e + 64 * wr + L.ar);            // access row of (qm, i) = mrow + 128 qm + 16 i
+  const uint32_t rstepC = 16u * (uint32_t)g.ldc * ES;                  // byte distance between row groups i, i + 1 (x 8 between qm)
+  const uint32_t rbaseC = mrow * (uint32_t)g.ldc * ES;
+
+  // the lane's 16 bias values (its accumulator columns, rounded to bf16 like autocast): four loads in flight together
+  float bw[2][2][4];
+  if constexpr (BIAS_EPI) {
+    const __amdgpu_buffer_rsrc_t rB = epi_rsrc(g.bias, g.bias ? Nu * 4u : 0u);
+    epi_u4 braw[2][2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) braw[pr][j] = epi_ld(rB, (uint32_t)(n0e + QN * pr + 32 * wc + 16 * j + 4 * lq) * 4u);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bw[pr][j][r] = round_bf(__uint_as_float(braw[pr][j][r]));
+  }
+
+  if constexpr (BF16_OUT) {
+    // bf16 outputs: after swap_strips a lane owns 8 consecutive columns of a 32-column strip pair -> one 16-byte access per (qm, i, pr)
+    uint32_t cC[2], cA[2];
+    bool okc[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const uint32_t n = (uint32_t)(n0e + QN * pr + 32 * wc + 8 * L.ac);
+      okc[pr] = n < Nu;
+      cC[pr] = rbaseC + n * 2u;
+      cA[pr] = mrow * (uint32_t)g.ldaux * 2u + n * 2u;
+    }
+    const uint32_t nrecA = (EPI == CRL_EPI_BF16) ? 0u : (uint32_t)(((size_t)(Mu - 1) * (uint32_t)g.ldaux + Nu) * 2u);
+    const __amdgpu_buffer_rsrc_t rA = epi_rsrc(g.aux, nrecA);
+    const uint32_t rstepA = 16u * (uint32_t)g.ldaux * 2u;
+    auto offC = [&](int qm, int i, int pr) { return okc[pr] ? cC[pr] + (uint32_t)(8 * qm + i) * rstepC : nrecC; };
+    auto offA = [&](int qm, int i, int pr) { return okc[pr] ? cA[pr] + (uint32_t)(8 * qm + i) * rstepA : nrecA; };
+    // saved pre-activations of the dGELU epilogue: ALL sixteen 16-byte loads of the lane are issued before the first use (64 VGPRs; the
+    // operand fragments of the K loop are dead here) -- one memory round trip per tile instead of one per batch.  Loads issued between
+    // the stores would also be counted behind them (vmcnt retires in issue order), i.e. wait for write acknowledgements.
+    epi_u4 hw[4][4];
+    if constexpr (EPI == CRL_EPI_BF16_DGELU) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hw[b][t] = epi_ld(rA, offA(b >> 1, 2 * (b & 1) + (t >> 1), t & 1));
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int qm = b >> 1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = 2 * (b & 1) + (t >> 1), pr = t & 1;
+        f32x2 v[2][2];     // [strip j][column pair]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 a4 = acc[qm][pr][i][j];
+          v[j][0] = f32x2{a4[0], a4[1]}; v[j][1] = f32x2{a4[2], a4[3]};
+          if constexpr (BIAS_EPI) { v[j][0] += f32x2{bw[pr][j][0], bw[pr][j][1]}; v[j][1] += f32x2{bw[pr][j][2], bw[pr][j][3]}; }
+        }
+        uint32_t x0, x1, y0, y1;
+        if constexpr (EPI == CRL_EPI_BF16) {
+          x0 = pack_bf2v(v[0][0]); x1 = pack_bf2v(v[0][1]); y0 = pack_bf2v(v[1][0]); y1 = pack_bf2v(v[1][1]);
+          swap_strips(x0, x1, y0, y1);
+          epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
+        } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
+          // h = bf16(v + b) is stored as is and expanded back to fp32 for the activation (the rounding the reference's autocast applies)
+          const uint32_t h00 = pack_bf2v(v[0][0]), h01 = pack_bf2v(v[0][1]), h10 = pack_bf2v(v[1][0]), h11 = pack_bf2v(v[1][1]);
+          x0 = h00; x1 = h01; y0 = h10; y1 = h11;
+          swap_strips(x0, x1, y0, y1);
+          epi_st(rA, offA(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
+          x0 = pack_bf2v(gelu2(unpack_bf2(h00))); x1 = pack_bf2v(gelu2(unpack_bf2(h01)));
+          y0 = pack_bf2v(gelu2(unpack_bf2(h10))); y1 = pack_bf2v(gelu2(unpack_bf2(h11)));
+          swap_strips(x0, x1, y0, y1);
+          epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
+        } else {   // dGELU: the 16-byte load holds 8 consecutive saved pre-activations; the exchange (an involution) returns this lane's own
+          const epi_u4 hm = L.to_math(hw[b][t]);
+          uint32_t a0 = hm[0], a1 = hm[1], b0 = hm[2], b1 = hm[3];
+          swap_strips(a0, a1, b0, b1);
+          x0 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][0])) * dgelu2(unpack_bf2(a0)));
+          x1 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][1])) * dgelu2(unpack_bf2(a1)));
+          y0 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][0])) * dgelu2(unpack_bf2(b0)));
+          y1 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][1])) * dgelu2(unpack_bf2(b1)));
+          swap_strips(x0, x1, y0, y1);
+          epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
+        }
+      }
+    }
+  } else {
+    // fp32 outputs: math lane (li, lq) owns columns 4 lq + 0..3 of each 16-column strip -> one 16-byte access per (qm, i, qn, j)
+    uint32_t cC[4], cR[4];
+    bool okc[4];
+    constexpr bool READS = (EPI == CRL_EPI_F32_RESID || EPI == CRL_EPI_F32_ACC);
+    const uint32_t ldr = (EPI == CRL_EPI_F32_RESID) ? (uint32_t)g.ldr : (uint32_t)g.ldc;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const uint32_t n = (uint32_t)(n0e + QN * (c4 >> 1) + 32 * wc + 16 * (c4 & 1) + 4 * L.ac);
+      okc[c4] = n < Nu;
+      cC[c4] = rbaseC + n * 4u;
+      cR[c4] = mrow * ldr * 4u + n * 4u;
+    }
+    const uint32_t nrecR = READS ? (uint32_t)(((size_t)(Mu - 1) * ldr + Nu) * 4u) : 0u;
+    const __amdgpu_buffer_rsrc_t rR = epi_rsrc(EPI == CRL_EPI_F32_RESID ? (const void*)g.resid : (const void*)g.C, nrecR);
+    const uint32_t rstepR = 16u * ldr * 4u;
+    auto offC = [&](int rg, int c4) { return okc[c4] ? cC[c4] + (uint32_t)rg * rstepC : nrecC; };
+    auto offR = [&](int rg, int c4) { return okc[c4] ? cR[c4] + (uint32_t)rg * rstepR : nrecR; };
+    // residual / accumulated-gradient tile in two halves (qm) of sixteen 16-byte loads; issue order L(0) L(1) S(0) S(1): the loads of
+    // the second half go out BEFORE the stores of the first (vmcnt retires in issue order, a load behind a store would wait for its
+    // write acknowledgement), and each half is one memory round trip instead of one per row group.
+    epi_u4 rv[2][16];
+    auto issue = [&](int h) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) rv[h][u] = epi_ld(rR, offR(8 * h + (u >> 2), u & 3));
+    };
+    auto half = [&](int qm) {
+      epi_u4 res[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = u >> 2, c4 = u & 3;
+        const f32x4 a4 = acc[qm][c4 >> 1][i][c4 & 1];
+        epi_u4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = a4[r];
+          if constexpr (BIAS_EPI) v += bw[c4 >> 1][c4 & 1][r];
+          if constexpr (EPI == CRL_EPI_F32_RESID) v = round_bf(v);
+          w[r] = __float_as_uint(v);
+        }
+        w = L.to_access(w);
+        if constexpr (READS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = __float_as_uint(__uint_as_float(rv[qm][u][r]) + __uint_as_float(w[r]));
+        }
+        res[u] = w;
+      }
+      if (READS && qm == 0) issue(1);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) epi_st(rC, offC(8 * qm + (u >> 2), u & 3), res[u]);
+    };
+    if constexpr (READS) issue(0);
+    half(0);
+    half(1);
+  }
+}
+
 template <int EPI, int QN>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2][2][4][2], int m0e, int n0e, int wr, int wc, int lane_e,
                                               size_t slab_off) {
@@ -102,6 +316,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
 #endif
   bool wide = false;
   if constexpr (BF16_OUT && G_WIDE) wide = ((g.N | g.ldc | ((EPI != CRL_EPI_BF16) ? g.ldaux : 0)) & 7) == 0;
+#ifndef G_EPI_BUF
+#define G_EPI_BUF 1   // 1 = branch-free buffer-access epilogue (epilogue_tile_buf) wherever 16-byte accesses apply; 0 = the predicated forms below (A/B)
+#endif
+  if (G_EPI_BUF && (wide || !BF16_OUT)) {
+    epilogue_tile_buf<EPI, QN>(g, acc, m0e, n0e, wr, wc, lane_e, slab_off);
+    return;
+  }
   if (wide) {
     // bf16 outputs, 16-byte accesses: no lane leaves the code before the lane exchanges (partners share li, i.e. the row);
     // loads use clamped coordinates, only the stores are predicated

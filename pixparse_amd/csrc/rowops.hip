@@ -72,55 +72,59 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // the block's 4 waves through LDS and written to ws[block][2][D]; ln_bwd_reduce sums the blocks.
 constexpr int LNB_MAXBLK = 512;
 
+// NV = float4 slots per lane (4: D <= 1024, 8: D <= 2048), COLSUM = also emit the column sums of dx16.  Both are compile-time so the
+// D = 1024 rows of the step keep ~110 VGPRs (4 waves / SIMD); with 8 slots and a run-time colsum flag the kernel sat at 2 waves /
+// SIMD and 48 KiB of LDS and took 148 us instead of 104 us per 49512 x 1024 launch (rocprofv3, r2 baseline).
+template <int NV, bool COLSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy32, const u16* __restrict__ dy16,
                                                      const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      int M, int D, float* __restrict__ dx32, int dx_acc,
-                                                     u16* __restrict__ dx16, float* __restrict__ ws, int want_colsum) {
+                                                     u16* __restrict__ dx16, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][NP][D], NP = 2 (+1 with the output column sums)
+  float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][D]: the NP partial kinds are combined one after the other
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
-  const int NP = want_colsum ? 3 : 2;
+  constexpr int NP = COLSUM ? 3 : 2;
   // ao: column sums of the bf16 gradient this kernel EMITS (dx16) = the bias gradient of the Linear whose output
   // gradient it is -- the rows are in registers anyway, so the separate colsum pass over dx16 disappears
-  float4 ag[LN_MAXV], ab[LN_MAXV], ao[LN_MAXV];
+  float4 ag[NV], ab[NV], ao[COLSUM ? NV : 1];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) { ag[i] = float4{0, 0, 0, 0}; ab[i] = float4{0, 0, 0, 0}; ao[i] = float4{0, 0, 0, 0}; }
+  for (int i = 0; i < NV; ++i) { ag[i] = float4{0, 0, 0, 0}; ab[i] = float4{0, 0, 0, 0}; if constexpr (COLSUM) ao[i] = float4{0, 0, 0, 0}; }
   for (int row = blockIdx.x * 4 + wave; row < M; row += nw) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     const size_t ro = (size_t)row * D;
     // All loads of a row are issued kind by kind BEFORE the arithmetic (fp32 dy, bf16 dy, x; gamma stays cached): the
     // wave then waits for one round trip per kind instead of one per 1-KB slot (the per-slot form measured 160 us for
     // 49512 x 1024 -- latency-bound at 2 waves per SIMD although it looked like 5 TB/s).
-    float4 gv[LN_MAXV], xh[LN_MAXV];
+    float4 gv[NV], xh[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) gv[i] = float4{0, 0, 0, 0};
+    for (int i = 0; i < NV; ++i) gv[i] = float4{0, 0, 0, 0};
     if (dy32) {
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) gv[i] = *reinterpret_cast<const float4*>(dy32 + ro + c);
       }
     }
-    uint2 hb[LN_MAXV];
+    uint2 hb[NV];
     if (dy16) {
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         hb[i] = uint2{0u, 0u};
         if (c < D) hb[i] = *reinterpret_cast<const uint2*>(dy16 + ro + c);
       }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       xh[i] = float4{mean, mean, mean, mean};
       if (c < D) xh[i] = *reinterpret_cast<const float4*>(x + ro + c);
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
         float4 d = gv[i];
@@ -140,17 +144,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       }
     }
     const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-    float4 old[LN_MAXV];
+    float4 old[NV];
     if (dx32 && dx_acc) {   // the accumulated residual gradient: one batch of loads, not a read-modify-write per slot
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         old[i] = float4{0, 0, 0, 0};
         if (c < D) old[i] = *reinterpret_cast<const float4*>(dx32 + ro + c);
       }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
         float4 o{rstd * (gv[i].x - c1 - xh[i].x * c2), rstd * (gv[i].y - c1 - xh[i].y * c2),
@@ -160,26 +164,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           *reinterpret_cast<float4*>(dx32 + ro + c) = o;
         }
         if (dx16) *reinterpret_cast<uint2*>(dx16 + ro + c) = uint2{pack_bf2(o.x, o.y), pack_bf2(o.z, o.w)};
-        if (want_colsum) { ao[i].x += round_bf(o.x); ao[i].y += round_bf(o.y); ao[i].z += round_bf(o.z); ao[i].w += round_bf(o.w); }
+        if constexpr (COLSUM) { ao[i].x += round_bf(o.x); ao[i].y += round_bf(o.y); ao[i].z += round_bf(o.z); ao[i].w += round_bf(o.w); }
       }
     }
   }
-  // block combine
+  // block combine: one partial kind at a time through a [4 waves][D] LDS buffer (16 KiB at D = 1024)
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < D) {
-      *reinterpret_cast<float4*>(red + (wave * NP + 0) * D + c) = ag[i];
-      *reinterpret_cast<float4*>(red + (wave * NP + 1) * D + c) = ab[i];
-      if (want_colsum) *reinterpret_cast<float4*>(red + (wave * NP + 2) * D + c) = ao[i];
+  for (int which = 0; which < NP; ++which) {
+    if (which) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        float4 v = ag[i];
+        if (which == 1) v = ab[i];
+        if constexpr (COLSUM) { if (which == 2) v = ao[i]; }
+        *reinterpret_cast<float4*>(red + wave * D + c) = v;
+      }
     }
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NP * D; idx += 256) {
-    const int which = idx / D, c = idx - which * D;
-    const float v = (red[(0 * NP + which) * D + c] + red[(1 * NP + which) * D + c]) +
-                    (red[(2 * NP + which) * D + c] + red[(3 * NP + which) * D + c]);
-    ws[(size_t)blockIdx.x * NP * D + idx] = v;
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+      ws[((size_t)blockIdx.x * NP + which) * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
   }
 }
 
@@ -511,8 +516,12 @@ extern "C" int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const
   const int nblk = (int)(blocks_for(M, 4) < (unsigned)LNB_MAXBLK ? blocks_for(M, 4) : LNB_MAXBLK);
   hipStream_t s = as_stream(stream);
   const int np = dx_colsum ? 3 : 2;
-  ln_bwd_kernel<<<nblk, 256, 4 * np * D * sizeof(float), s>>>(dy_f32, (const u16*)dy_bf16, x, gamma, mean, rstd, (int)M, (int)D,
-                                                              dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws, dx_colsum ? 1 : 0);
+  const size_t lds = 4 * D * sizeof(float);
+#define LNB_LAUNCH(NV, CS) ln_bwd_kernel<NV, CS><<<nblk, 256, lds, s>>>(dy_f32, (const u16*)dy_bf16, x, gamma, mean, rstd, (int)M, (int)D, \
+                                                                     dx_f32, dx_accumulate, (u16*)dx_bf16, (float*)ws)
+  if (D <= 1024) { if (dx_colsum) LNB_LAUNCH(4, true); else LNB_LAUNCH(4, false); }
+  else { if (dx_colsum) LNB_LAUNCH(8, true); else LNB_LAUNCH(8, false); }
+#undef LNB_LAUNCH
   CRL_LAUNCH_CHECK("crl_layernorm_bwd");
   if (dgamma || dbeta || dx_colsum) {
     ln_bwd_reduce<<<blocks_for(np * D, 16), 256, 0, s>>>((const float*)ws, nblk, (int)D, dgamma, dbeta, acc_wgrad, dx_colsum, np);
