@@ -44,6 +44,23 @@ def test_library_exports_every_declared_symbol():
     assert hip.query('crl_grad_norm_ws_bytes') > 0
 
 
+def test_swin_window_attention_is_compiled_to_mfma():
+    """north_star: the Swin window attention runs QK^T / PV on the matrix cores -- the gfx950 code hipcc emits for swin.hip holds
+    v_mfma_f32_32x32x16_bf16 (8 + 8 forward, 40 backward per window and head) and the transposed LDS reads that feed them"""
+    import subprocess, tempfile
+    from pixparse_amd import build as b
+    src = os.path.join(b.CSRC, 'swin.hip')
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'swin.s')
+        r = subprocess.run([b._hipcc()] + b.FLAGS + ['--cuda-device-only', '-S', src, '-o', out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        asm = open(out).read()
+    fwd = asm[asm.index('swin_attn_kernelILb0'):asm.index('swin_attn_kernelILb1')]
+    bwd = asm[asm.index('swin_attn_kernelILb1'):]
+    assert fwd.count('v_mfma_f32_32x32x16_bf16') >= 16 and bwd.count('v_mfma_f32_32x32x16_bf16') >= 40
+    assert 'ds_read_b64_tr_b16' in fwd and 'ds_read_b64_tr_b16' in bwd
+
+
 def test_binding_loads_torch_before_the_hip_library():
     """regression: dlopen of libcruller_hip.so before torch maps a second HIP runtime (torch ships its own libamdhip64) and
     every later launch fails with "no ROCm-capable device" -- build() followed by smoke() in one process hit this"""

@@ -478,7 +478,7 @@ def test_attention_forced_rescale(dev):
     close(lse, lref, 1e-3, 2e-3, 'spiked lse')
 
 
-@pytest.mark.parametrize('Hf,Wf,heads,w,shift', [(14, 14, 3, 7, 0), (14, 14, 3, 7, 3), (8, 16, 2, 4, 2), (7, 7, 4, 7, 0)])
+@pytest.mark.parametrize('Hf,Wf,heads,w,shift', [(14, 14, 3, 7, 0), (14, 14, 3, 7, 3), (8, 16, 2, 4, 2), (7, 7, 4, 7, 0), (16, 16, 2, 8, 4), (21, 14, 1, 7, 3)])
 def test_swin_window_attention(dev, Hf, Wf, heads, w, shift):
     from oracle import ref_cpu as R
     from pixparse_amd import ops
