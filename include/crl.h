@@ -48,7 +48,8 @@ enum { CRL_NT = 0, CRL_NN = 1, CRL_TN = 2 };
 enum { CRL_EPI_BF16 = 0, CRL_EPI_BF16_GELU = 1, CRL_EPI_BF16_DGELU = 2, CRL_EPI_F32_RESID = 3,
        CRL_EPI_F32 = 4, CRL_EPI_F32_ACC = 5 };
 /* ws (optional, >= crl_gemm_ws_bytes(...)): fp32 scratch that lets the wgrad layout split its long
- * contraction over several workgroups per output tile (deterministic slab reduce, no atomics). */
+ * contraction over several workgroups per output tile (deterministic slab reduce, no atomics); the NT / NN
+ * layouts use it for the few remainder rows of the wave-quantisation split when K >= 2048 (0 = not needed). */
 size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K);
 /* kernel selection override for tests / A-B runs: 0 = auto (the 256-row kernels when they fill the chip, else 128x128),
  * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent

@@ -154,6 +154,31 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, s
   *p = s;
 }
 
+// the same slab sum followed by a forward / dgrad epilogue (bias + bf16 store, or bias + bf16 rounding + fp32 residual): used for the
+// few remainder rows of the wave-quantisation split when their contraction is long (see crl_gemm_bf16)
+template <int EPI>
+__global__ void splitk_reduce_epi_kernel(const float* __restrict__ ws, int nsplit, size_t slab, int M, int N, const float* __restrict__ bias,
+                                         void* __restrict__ C, int ldc, const float* __restrict__ resid, int ldr) {
+  const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (idx >= (size_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  float4 s = *reinterpret_cast<const float4*>(ws + idx);
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + idx);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (bias) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    s.x += round_bf(b.x); s.y += round_bf(b.y); s.z += round_bf(b.z); s.w += round_bf(b.w);
+  }
+  if constexpr (EPI == CRL_EPI_BF16) {
+    *reinterpret_cast<uint2*>((u16*)C + (size_t)m * ldc + n) = uint2{pack_bf2(s.x, s.y), pack_bf2(s.z, s.w)};
+  } else {
+    const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)m * ldr + n);
+    *reinterpret_cast<float4*>((float*)C + (size_t)m * ldc + n) = float4{r.x + round_bf(s.x), r.y + round_bf(s.y), r.z + round_bf(s.z), r.w + round_bf(s.w)};
+  }
+}
+
 template <int LAYOUT, int EPI>
 int launch_bk(const GemmArgs& a, int bk, int nsplit, hipStream_t s) {
   const dim3 grid(a.ntm * a.ntn, nsplit);
@@ -216,6 +241,39 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
   return p;
 }
 
+// Wave quantisation: the 256x256 kernel runs one workgroup per CU, so R*ntn tiles cost ceil(R*ntn/256) full tile times.  When
+// trimming a few row tiles lands on a whole number of waves, the big kernel takes the first 256*R rows and the remaining rows
+// (< 9 row tiles) go to the 128x128 kernel, whose small tiles pack 2 per CU.  Returns R, or -1 for "no split".
+static int64_t quant_rows(int layout, int64_t M, int64_t N) {
+  const int64_t ntn = (N + 255) / 256, rmax = M / 256;
+  int64_t best_r = -1;
+  double best_cost = (double)((((M + 255) / 256) * ntn + 255) / 256);   // in units of one 256-tile time
+  if (layout == CRL_TN) return -1;
+  for (int64_t r = rmax; r >= 1 && r >= rmax - 8; --r) {
+    const int64_t rem = M - 256 * r;
+    if (rem <= 0) continue;
+    const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 511) / 512);
+    const double cost = (double)((r * ntn + 255) / 256) + small;
+    if (cost < best_cost - 0.2) { best_cost = cost; best_r = r; }
+  }
+  return best_r;
+}
+// The remainder launch has few tiles (360 rows x N of the cfg-3 encoder: 24 to 96) and, for fc2 / the fc1 and qkv dgrads, a long
+// contraction: 24 workgroups walking 64 K tiles leave 90 % of the chip idle for ~60 us.  Its contraction is then cut into up to 8
+// chunks (fp32 slabs in the caller's scratch + a reduce that applies the epilogue); 1 = no split.
+#ifndef G_REM_SPLIT
+#define G_REM_SPLIT 1
+#endif
+static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K) {
+  if (!G_REM_SPLIT || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
+  const int64_t nk = K / 64, tiles = ((rem + 127) / 128) * ((N + 127) / 128);
+  if (nk < 32 || tiles >= 128) return 1;
+  int ns = (int)(384 / tiles);
+  if (ns > 8) ns = 8;
+  while (ns > 1 && nk / ns < 8) --ns;
+  return ns;
+}
+
 extern "C" int crl_gemm_set_policy(int policy) {
   if (policy < 0 || policy > 3) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
   g_policy = policy;
@@ -224,7 +282,15 @@ extern "C" int crl_gemm_set_policy(int policy) {
 
 extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
   const Plan p = plan_gemm(layout, epilogue, M, N, K, true);
-  return p.nsplit > 1 ? (size_t)p.nsplit * M * N * sizeof(float) : 0;
+  if (p.nsplit > 1) return (size_t)p.nsplit * M * N * sizeof(float);
+  if (p.big && g_policy != 3) {
+    const int64_t r = quant_rows(layout, M, N);
+    if (r > 0) {
+      const int ns = rem_split(epilogue, M - 256 * r, N, K);
+      if (ns > 1) return (size_t)ns * (M - 256 * r) * N * sizeof(float);
+    }
+  }
+  return 0;
 }
 
 extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
@@ -292,21 +358,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     return 0;
   }
   if (p.big) {
-    // Wave quantisation: the 256x256 kernel runs one workgroup per CU, so R*ntn tiles cost ceil(R*ntn/256) full tile
-    // times.  When trimming a few row tiles lands on a whole number of waves, the big kernel takes the first 256*R rows
-    // and the remaining rows (< 9 row tiles) go to the 128x128 kernel, whose small tiles pack 2 per CU.
-    const int64_t ntn = a.ntn, rmax = M / 256;
-    int64_t best_r = -1;
-    double best_cost = (double)((((M + 255) / 256) * ntn + 255) / 256);   // in units of one 256-tile time
-    if (layout != CRL_TN) {
-      for (int64_t r = rmax; r >= 1 && r >= rmax - 8; --r) {
-        const int64_t rem = M - 256 * r;
-        if (rem <= 0) continue;
-        const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 511) / 512);
-        const double cost = (double)((r * ntn + 255) / 256) + small;
-        if (cost < best_cost - 0.2) { best_cost = cost; best_r = r; }
-      }
-    }
+    const int64_t best_r = quant_rows(layout, M, N);
     if (best_r < 0) return crl_gemm256_launch(layout, epilogue, a, 1, s);
     const int64_t m1 = 256 * best_r;
     GemmArgs big = a;
@@ -322,6 +374,23 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     rest.a_bytes = (uint32_t)(((M - m1 - 1) * lda + K) * 2);
     rest.ntm = (int)((M - m1 + BM - 1) / BM); rest.ntn = (int)((N + BN - 1) / BN);
     rest.kchunk = (int)((K + 63) / 64);
+    const int64_t rem = M - m1;
+    const int ns = rem_split(epilogue, rem, N, K);
+    if (ns > 1 && ws && ws_bytes >= (size_t)ns * rem * N * sizeof(float)) {
+      GemmArgs sl = rest;
+      sl.bias = nullptr; sl.aux = nullptr; sl.resid = nullptr;
+      sl.C = ws; sl.ldc = (int)N; sl.slab_stride = (size_t)rem * N;
+      sl.kchunk = (int)((K / 64 + ns - 1) / ns);
+      const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
+      if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
+      const unsigned blocks = (unsigned)(((size_t)rem * N / 4 + 255) / 256);
+      if (epilogue == CRL_EPI_BF16)
+        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0);
+      else
+        splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, rest.resid, (int)ldr);
+      CRL_LAUNCH_CHECK("crl_gemm_bf16(remainder reduce)");
+      return 0;
+    }
     switch (layout) {
       case CRL_NT: return launch_epi<CRL_NT>(rest, epilogue, 64, 1, s);
       default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, s);

@@ -35,11 +35,10 @@ def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: in
          ldaux: int = 0, resid: Optional[torch.Tensor] = None, ldr: int = 0) -> None:
     _chk(A, BF16, 'gemm A')
     _chk(B, BF16, 'gemm B')
-    ws, wsb = None, 0
-    if layout == TN:
-        wsb = hip.query('crl_gemm_ws_bytes', layout, epi, M, N, K)
-        if wsb:
-            ws = _gemm_scratch.get(wsb, A.device)
+    ws = None
+    wsb = hip.query('crl_gemm_ws_bytes', layout, epi, M, N, K)   # wgrad split-K slabs, or the split remainder rows of a forward / dgrad GEMM
+    if wsb:
+        ws = _gemm_scratch.get(wsb, A.device)
     hip.call('crl_gemm_bf16', layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(C), ldc, _p(aux), ldaux,
              _p(resid), ldr, _p(ws), wsb, _stream())
 

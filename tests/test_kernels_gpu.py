@@ -216,6 +216,31 @@ def test_gemm_wave_quantisation_split(dev):
     close(out, dy.float() @ w2.float(), 1e-2, 1e-2, 'split NN')
 
 
+def test_gemm_remainder_rows_split_contraction(dev):
+    """auto policy with a long contraction (K = 2048 / 3072): the remainder rows of the wave-quantisation split (few 128-tiles) run as
+    split-K slabs in the scratch + a reduce that applies the epilogue (bias + bf16, bias + bf16 rounding + fp32 residual)"""
+    from pixparse_amd import hip, ops
+    M, N = 256 * 64 + 232, 1024
+    for K in (2048, 3072):
+        assert hip.query('crl_gemm_ws_bytes', hip.NT, ops.EPI_F32_RESID, M, N, K) > 0
+        assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, K) > 0
+        assert hip.query('crl_gemm_ws_bytes', hip.NT, ops.EPI_BF16_GELU, M, N, K) == 0
+        x = rnd((M, K), dev, 1.0, 1, BF16)
+        w = rnd((N, K), dev, 0.05, 2, BF16)
+        bias = rnd((N,), dev, 0.5, 3)
+        ref = x.float() @ w.float().t() + bias.to(BF16).float()
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out)
+        close(out, ref, 1e-2, 2e-2, 'remainder split bf16')
+        y = rnd((M, N), dev, 1.0, 4)
+        want = y + ref.to(BF16).float()
+        ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+        close(y, want, 1e-2, 3e-2, 'remainder split resid')
+        w2 = rnd((K, N), dev, 0.05, 6, BF16)        # NN: out[M, N] = x[M, K] @ w2[K, N]
+        ops.linear_dgrad(x, w2, out)
+        close(out, x.float() @ w2.float(), 1e-2, 2e-2, 'remainder split NN')
+
+
 def test_gemm_256_splitk_wgrad(dev):
     from pixparse_amd import hip, ops
     Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
