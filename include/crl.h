@@ -233,6 +233,20 @@ int crl_cast_pad_bf16(const float* src, void* dst, int64_t R, int64_t C, int64_t
 /* y_f32 (+)= float(x_bf16), elementwise (gradient joins). */
 int crl_add_bf16_to_f32(const void* x_bf16, float* y, int64_t n, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------- dropout (opt-in, off in parity runs and bench.py)
+ * ref: transformers BartDecoder / BartDecoderLayer nn.functional.dropout(hidden_states, p=self.dropout, training=self.training)
+ * (modeling_bart.py:362,377,384-386,654): live in the reference only for a decoder built with pretrained=False.
+ * Stateless mask: element i keeps its value (scaled by 1/(1-p)) iff the 16-bit Philox4x32-10 uniform of (seed, step, site, i) is
+ * >= p * 65536, so the backward pass regenerates it from the same triple.  n: multiple of 8; in place allowed.
+ *   crl_dropout      y = dropout(x); bf16 (is_f32 = 0) or fp32 (is_f32 = 1, optional bf16 copy of the result in y_bf16)
+ *   crl_dropout_add  out(f32) = resid(f32) + bf16(dropout(x_bf16))        (residual join behind a dropped branch)
+ *   crl_dropout_mask keep[i] = 0 / 1 as bytes (tests: lets the CPU oracle apply the identical mask) */
+int crl_dropout(const void* x, void* y, int64_t n, int is_f32, void* y_bf16, float p, uint64_t seed, uint32_t step, uint32_t site,
+                void* stream);
+int crl_dropout_add(const void* x_bf16, const float* resid, float* out, int64_t n, float p, uint64_t seed, uint32_t step,
+                    uint32_t site, void* stream);
+int crl_dropout_mask(void* keep_u8, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream);
+
 /* ---------------------------------------------------------------- image preprocessing
  * ref: task/task_cruller_pretrain.py:132-143  ToTensor -> Resize(image_size, BICUBIC, antialias=True) -> Normalize.
  * img: uint8 [H, W, C] (decoded page); out: fp32 [C, Ho, Wo]; tmp: fp32 scratch [C, H, Wo].

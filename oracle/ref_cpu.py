@@ -312,12 +312,18 @@ def swin_param_shapes(arch: dict, in_chans: int, img_size: Tuple[int, int]) -> D
 # --------------------------------------------------------------------------------------
 def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_ids: Tensor,
                          enc: Tensor, policy: str = 'bf16', prefix: str = '',
-                         fast_attn: bool = False) -> Tensor:
+                         fast_attn: bool = False, drop=None) -> Tensor:
     """BartForCausalLM(input_ids, encoder_hidden_states=enc).logits  [B, T, V].
 
     Pure causal self-attention (the reference passes no attention_mask), unmasked cross
-    attention, post-LN layers, learned positions with offset 2, embed scale 1.0, dropout off.
+    attention, post-LN layers, learned positions with offset 2, embed scale 1.0.
+    Dropout (modeling_bart.py:362,377,384-386,654; live in the reference only for a train-mode decoder) is off unless
+    `drop(site, tensor)` is given: it is applied to the embedding LayerNorm output (site 0) and to the three branch outputs of
+    layer i before their residual joins (sites 1 + 3 i + {0: self-attention, 1: cross attention, 2: fc2}) -- the hidden-state
+    dropout sites of BartDecoder / BartDecoderLayer; the caller supplies the mask (tests: the GPU kernel's own Philox mask).
     """
+    if drop is None:
+        drop = lambda site, t: t
     D, H = arch['d_model'], arch['heads']
     d = D // H
     eps = arch['ln_eps']
@@ -327,7 +333,7 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
     S = enc.shape[1]
     h = g(dp + 'embed_tokens.weight')[input_ids].float()
     h = h + g(dp + 'embed_positions.weight')[torch.arange(T) + 2].float()
-    h = _layer_norm(h, g(dp + 'layernorm_embedding.weight'), g(dp + 'layernorm_embedding.bias'), eps)
+    h = drop(0, _layer_norm(h, g(dp + 'layernorm_embedding.weight'), g(dp + 'layernorm_embedding.bias'), eps))
 
     def heads(t, n):
         return t.view(B, n, H, d).transpose(1, 2)
@@ -340,7 +346,7 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
         v = _linear(h, g(lp + 'self_attn.v_proj.weight'), g(lp + 'self_attn.v_proj.bias'), policy)
         o = _attention(heads(q, T), heads(k, T), heads(v, T), d ** -0.5, True, policy, fast=fast_attn)
         o = o.transpose(1, 2).reshape(B, T, D)
-        o = _linear(o, g(lp + 'self_attn.out_proj.weight'), g(lp + 'self_attn.out_proj.bias'), policy)
+        o = drop(1 + 3 * i, _linear(o, g(lp + 'self_attn.out_proj.weight'), g(lp + 'self_attn.out_proj.bias'), policy))
         h = _layer_norm(h + o.float(), g(lp + 'self_attn_layer_norm.weight'),
                         g(lp + 'self_attn_layer_norm.bias'), eps)
         # cross attention (K/V of the encoder states recomputed in every layer)
@@ -349,12 +355,12 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
         v = _linear(enc, g(lp + 'encoder_attn.v_proj.weight'), g(lp + 'encoder_attn.v_proj.bias'), policy)
         o = _attention(heads(q, T), heads(k, S), heads(v, S), d ** -0.5, False, policy, fast=fast_attn)
         o = o.transpose(1, 2).reshape(B, T, D)
-        o = _linear(o, g(lp + 'encoder_attn.out_proj.weight'), g(lp + 'encoder_attn.out_proj.bias'), policy)
+        o = drop(2 + 3 * i, _linear(o, g(lp + 'encoder_attn.out_proj.weight'), g(lp + 'encoder_attn.out_proj.bias'), policy))
         h = _layer_norm(h + o.float(), g(lp + 'encoder_attn_layer_norm.weight'),
                         g(lp + 'encoder_attn_layer_norm.bias'), eps)
         # FFN
         f = _gelu(_linear(h, g(lp + 'fc1.weight'), g(lp + 'fc1.bias'), policy))
-        f = _linear(f, g(lp + 'fc2.weight'), g(lp + 'fc2.bias'), policy)
+        f = drop(3 + 3 * i, _linear(f, g(lp + 'fc2.weight'), g(lp + 'fc2.bias'), policy))
         h = _layer_norm(h + f.float(), g(lp + 'final_layer_norm.weight'), g(lp + 'final_layer_norm.bias'), eps)
     # tied LM head, no bias
     return _linear(h, g(dp + 'embed_tokens.weight'), None, policy)
@@ -420,14 +426,14 @@ def init_params(spec: ModelSpec, seed: int = 0, std: float = 0.02) -> Dict[str, 
 
 
 def cruller_forward(p: Dict[str, Tensor], spec: ModelSpec, image: Tensor, text_input: Tensor,
-                    policy: str = 'bf16', fast_attn: bool = False) -> Tensor:
+                    policy: str = 'bf16', fast_attn: bool = False, drop=None) -> Tensor:
     """models/cruller.py:14-21 -> logits [B, T, V]."""
     if spec.enc_kind == 'swin':
         enc = swin_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.')
     else:
         enc = vit_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.', fast_attn=fast_attn)
     return bart_decoder_forward(p, spec.dec_arch, spec.n_layers, text_input, enc, policy,
-                                prefix='text_decoder.trunk.', fast_attn=fast_attn)
+                                prefix='text_decoder.trunk.', fast_attn=fast_attn, drop=drop)
 
 
 def encode_image(p: Dict[str, Tensor], spec: ModelSpec, image: Tensor, policy: str = 'bf16') -> Tensor:
@@ -466,9 +472,9 @@ def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> T
 
 
 def cruller_loss(p, spec: ModelSpec, image: Tensor, text_input: Tensor, text_target: Tensor,
-                 policy: str = 'bf16', accum_steps: int = 1, fast_attn: bool = False) -> Tensor:
+                 policy: str = 'bf16', accum_steps: int = 1, fast_attn: bool = False, drop=None) -> Tensor:
     """the `_forward` closure, task_cruller_pretrain.py:247-257 (inputs already shifted)."""
-    logits = cruller_forward(p, spec, image, text_input, policy, fast_attn)
+    logits = cruller_forward(p, spec, image, text_input, policy, fast_attn, drop)
     loss = cross_entropy(logits, text_target)
     if accum_steps > 1:
         loss = loss / accum_steps

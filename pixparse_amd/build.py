@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcruller_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm2x.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'capi.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm2x.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'dropout.hip', 'capi.cpp']
 HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", os.path.join('..', '..', 'include', 'crl.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # per-file extras: hipcc's SLP vectoriser packs the softmax / dS multiplies of the attention kernels into v_pk_mul_f32 on

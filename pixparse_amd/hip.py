@@ -5,7 +5,7 @@ The reference-side equivalent of this file is shown in INTEGRATION.md.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 # torch FIRST: it ships its own libamdhip64; if libcruller_hip.so were dlopen'ed before torch, /opt/rocm's copy would be
 # mapped as well and the process would hold two HIP runtimes -- launches through the second one fail with
@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libcruller_hip.so')
 
 P, I, L, F, Z = c_void_p, c_int, c_int64, c_float, c_size_t
+U32, U64 = c_uint32, c_uint64
 
 # name -> (restype, argtypes); mirrors include/crl.h one to one
 SIGNATURES = {
@@ -57,6 +58,9 @@ SIGNATURES = {
     'crl_cast_bf16': (I, [P, P, L, P]),
     'crl_cast_pad_bf16': (I, [P, P, L, L, L, P]),
     'crl_add_bf16_to_f32': (I, [P, P, L, I, P]),
+    'crl_dropout': (I, [P, P, L, I, P, F, U64, U32, U32, P]),
+    'crl_dropout_add': (I, [P, P, P, L, F, U64, U32, U32, P]),
+    'crl_dropout_mask': (I, [P, L, F, U64, U32, U32, P]),
     'crl_image_preprocess_u8': (I, [P, I, I, I, P, P, P, I, P, P, P, I, P, P, P, P, I, I, P]),
 }
 

@@ -409,6 +409,29 @@ class BartEngine(_Base):
         self.D, self.heads, self.F = arch['d_model'], arch['heads'], arch['ffn']
         if self.D != self.heads * ops.HEAD_DIM:
             raise ValueError(f"BART arch d_model {self.D} / heads {self.heads}: the attention kernels are built for head_dim {ops.HEAD_DIM}")
+        # hidden-state dropout of the NEXT forward / backward pair (ops.DropSpec) or None; set by Cruller when training dropout
+        # is switched on.  Sites: 0 = embedding LayerNorm output, 1 + 3 i + {0, 1, 2} = self-attention /
+        # cross-attention / fc2 branch of layer i before its residual join (modeling_bart.py:362,377,384-386,654).
+        self.drop: Optional[ops.DropSpec] = None
+
+    def _branch(self, x, w, b, out, resid, site):
+        """out(f32) = resid + [dropout](bf16(x @ w^T + b)): the residual join behind an attention / FFN branch"""
+        if self.drop is None:
+            ops.linear_fwd(x, w, b, out, EPI_F32_RESID, resid=resid)
+        else:
+            tmp = self.buf('drop.tmp', (x.shape[0], w.shape[0]), BF16)
+            ops.linear_fwd(x, w, b, tmp)
+            ops.dropout_add(tmp, resid, out, self.drop, site)
+
+    def _branch_bwd(self, ln_name, key, x, dy32, dyb, dx32, dxb, bias_of, site):
+        """LayerNorm backward behind a residual join; dxb = the (dropped) gradient of the branch's Linear output, whose bias
+        gradient is its column sum (fused into the LayerNorm backward when there is no mask to apply first)"""
+        if self.drop is None:
+            self.ln_bwd(ln_name, key, x, dy32, dyb, dx32, False, dxb, bias_of=bias_of)
+        else:
+            self.ln_bwd(ln_name, key, x, dy32, dyb, dx32, False, dxb)
+            ops.dropout(dxb, dxb, self.drop, site)
+            ops.colsum(dxb, self.G(bias_of + '.bias'), True)
 
     @staticmethod
     def param_shapes(arch, n_layers, vocab, max_pos):
@@ -456,6 +479,8 @@ class BartEngine(_Base):
         emb = self.buf('emb', (M, D), F32)
         ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2)
         h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'ln_emb', eps, want_f32=True, want_bf16=True)
+        if self.drop is not None:
+            ops.dropout(h, h, self.drop, 0, y_bf16=hb)
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
@@ -465,7 +490,7 @@ class BartEngine(_Base):
             lse1 = self.buf(k + '.lse1', (B, H, T), F32)
             ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True)
             t1 = self.buf(k + '.t1', (M, D), F32)
-            ops.linear_fwd(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
+            self._branch(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, h, 1 + 3 * i)
             h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
             q2 = self.buf(k + '.q2', (M, D), BF16)
             ops.linear_fwd(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
@@ -476,13 +501,13 @@ class BartEngine(_Base):
             lse2 = self.buf(k + '.lse2', (B, H, T), F32)
             ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False)
             t2 = self.buf(k + '.t2', (M, D), F32)
-            ops.linear_fwd(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
+            self._branch(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, h1, 2 + 3 * i)
             h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
             pre = self.buf(k + '.pre', (M, F_), BF16)
             act = self.buf(k + '.act', (M, F_), BF16)
             ops.linear_fwd(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU, aux=pre)
             t3 = self.buf(k + '.t3', (M, D), F32)
-            ops.linear_fwd(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, EPI_F32_RESID, resid=h2)
+            self._branch(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, h2, 3 + 3 * i)
             self.bufs.t[self.tag + '.' + k + '.hb'] = hb
             h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, k + '.ln3', eps, True, True)
         self.h_last16 = hb
@@ -586,13 +611,13 @@ class BartEngine(_Base):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             g = lambda n: Tb[tg + k + n]
             # ---- h_out = LN3(t3), t3 = h2 + fc2(gelu(fc1(h2b)))
-            self.ln_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, False, dtb, bias_of=lp + 'fc2')
+            self._branch_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, dtb, lp + 'fc2', 3 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.pre'))
             self.lin_wgrad(lp + 'fc2', dtb, g('.act'), has_bias=False)
             ops.linear_dgrad(dpre, self.W(lp + 'fc1.weight'), dhb)
             self.lin_wgrad(lp + 'fc1', dpre, g('.ln2.y16'))
             # ---- h2 = LN2(t2), t2 = h1 + out_c(attn(q_c(h1b), kv_c(enc)))
-            self.ln_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, False, dtb, bias_of=lp + 'encoder_attn.out_proj')
+            self._branch_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, dtb, lp + 'encoder_attn.out_proj', 2 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'encoder_attn.out_proj.weight'), do)
             self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'), has_bias=False)
             kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
@@ -604,7 +629,7 @@ class BartEngine(_Base):
             ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
             ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
-            self.ln_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, False, dtb, bias_of=lp + 'self_attn.out_proj')
+            self._branch_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, dtb, lp + 'self_attn.out_proj', 1 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'self_attn.out_proj.weight'), do)
             self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'), has_bias=False)
             q3, dq3 = g('.qkv').view(B, T, 3 * D), dqkv.view(B, T, 3 * D)
@@ -618,6 +643,9 @@ class BartEngine(_Base):
                 on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')
         # ---- h0 = LN(emb)
         demb = self.buf('demb', (M, D), F32)
+        if self.drop is not None:      # the mask of site 0 on both gradient streams arriving at the embedding LayerNorm output
+            ops.dropout(dy32, dy32, self.drop, 0)
+            ops.dropout(dyb, dyb, self.drop, 0)
         self.ln_bwd(dp + 'layernorm_embedding', 'ln_emb', Tb[tg + 'emb'], dy32, dyb, demb, False, None)
         ops.embed_bwd(self.ids, demb, self.G(dp + 'embed_tokens.weight'), self.G(dp + 'embed_positions.weight'), 2, True)
         if on_layer_done:

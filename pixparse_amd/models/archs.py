@@ -13,7 +13,7 @@ SWIN_ARCHS = {
                                          mlp_ratio=4, ln_eps=1e-5, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)),
 }
 BART_ARCHS = {
-    'facebook/bart-base': dict(d_model=768, heads=12, ffn=3072, ln_eps=1e-5, vocab=50265, dropout=0.1),
+    'facebook/bart-base': dict(d_model=768, heads=12, ffn=3072, ln_eps=1e-5, vocab=50265, dropout=0.1, attention_dropout=0.1, activation_dropout=0.1),
     'facebook/bart-large': dict(d_model=1024, heads=16, ffn=4096, ln_eps=1e-5, vocab=50265, dropout=0.1),
 }
 

@@ -244,9 +244,21 @@ class Cruller(nn.Module):
         enc32, enc16 = enc.forward(image_input.contiguous().float())
         return enc32, enc16
 
-    def forward(self, image_input: torch.Tensor, text_input: torch.Tensor):
+    def set_train_dropout(self, enabled: bool, seed: int = 0):
+        """Opt-in hidden-state dropout of the text decoder inside forward_loss() / backward(): the reference's
+        decoder runs it only when built with pretrained=False (BartForCausalLM from_config stays in train mode, p = config.dropout;
+        text_decoder_hf.py:25-33); parity runs, bench.py and every eval / generation path keep it off.  The mask of micro-step s is
+        a pure function of (seed, s, site, element) -- crl_dropout in include/crl.h."""
+        p = float(self.dec_arch.get('dropout', 0.0))
+        if enabled and (self.dec_arch.get('attention_dropout', 0.0) or self.dec_arch.get('activation_dropout', 0.0)):
+            raise NotImplementedError(f'{self.cfg.text_decoder.name}: attention / activation dropout are not implemented (hidden-state dropout only)')
+        self._drop = (p, int(seed)) if enabled and p > 0 else None
+        self._drop_step = 0
+
+    def forward(self, image_input: torch.Tensor, text_input: torch.Tensor, _drop=None):
         """ref models/cruller.py:14-21 -> output['logits'] bf16 [B, T, V] (a view of the padded logits buffer)."""
         enc, dec, _ = self._ensure_engines()
+        dec.drop = _drop
         enc32, enc16 = self.encode(image_input)
         B, T = text_input.shape
         logits = dec.forward(text_input.contiguous(), enc16, enc.out_tokens())
@@ -340,7 +352,11 @@ class Cruller(nn.Module):
         """forward + shifted-token cross-entropy; leaves d(loss*grad_mul)/dlogits in the logits buffer.
         returns the device scalar loss (fp32, = mean NLL * loss_mul)."""
         enc, dec, bufs = self._ensure_engines()
-        self.forward(image_input, text_input)
+        drop = None
+        if getattr(self, '_drop', None) is not None:
+            drop = ops.DropSpec(self._drop[0], self._drop[1], self._drop_step)
+            self._drop_step += 1
+        self.forward(image_input, text_input, _drop=drop)   # dec.drop stays set for the matching backward()
         B, T = text_input.shape
         M = B * T
         logits = bufs.t['dec.logits']

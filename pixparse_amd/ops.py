@@ -259,5 +259,32 @@ def cast_pad_bf16(src, dst, R: int, C: int, Cp: int) -> None:
     hip.call('crl_cast_pad_bf16', _p(src), _p(dst), R, C, Cp, _stream())
 
 
+class DropSpec:
+    """(p, seed, step) of one forward / backward pair; site ids are chosen by the caller (one per dropout call site)"""
+
+    def __init__(self, p: float, seed: int, step: int):
+        self.p, self.seed, self.step = float(p), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 32 - 1)
+
+
+def dropout(x: torch.Tensor, y: torch.Tensor, d: DropSpec, site: int, y_bf16: Optional[torch.Tensor] = None) -> None:
+    """y = dropout(x) (bf16 or fp32, in place allowed); fp32 inputs may emit a bf16 copy of the result"""
+    assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
+    hip.call('crl_dropout', _p(x), _p(y), x.numel(), int(x.dtype == F32), _p(y_bf16), d.p, d.seed, d.step, site, _stream())
+
+
+def dropout_add(x_bf16: torch.Tensor, resid: torch.Tensor, out: torch.Tensor, d: DropSpec, site: int) -> None:
+    """out(f32) = resid(f32) + bf16(dropout(x_bf16))"""
+    _chk(x_bf16, BF16, 'dropout_add x')
+    _chk(resid, F32, 'dropout_add resid')
+    assert x_bf16.is_contiguous() and resid.is_contiguous() and out.is_contiguous()
+    hip.call('crl_dropout_add', _p(x_bf16), _p(resid), _p(out), x_bf16.numel(), d.p, d.seed, d.step, site, _stream())
+
+
+def dropout_mask(n: int, d: DropSpec, site: int, device) -> torch.Tensor:
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    hip.call('crl_dropout_mask', _p(keep), n, d.p, d.seed, d.step, site, _stream())
+    return keep
+
+
 def add_bf16_to_f32(x_bf16, y, accumulate: bool) -> None:
     hip.call('crl_add_bf16_to_f32', _p(x_bf16), _p(y), x_bf16.numel(), int(accumulate), _stream())

@@ -29,6 +29,9 @@ class TaskCrullerPretrainCfg(TaskTrainCfg):
     model_name: Optional[str] = None
     model: ModelCfg = field(default_factory=ModelCfg)
     tokenizer: TokenizerCfg = field(default_factory=TokenizerCfg)
+    # not a reference field: the reference's decoder drops hidden states (p = 0.1) exactly when it was built with pretrained=False
+    # (from_config leaves train mode); here that behaviour is an explicit switch, off by default
+    decoder_dropout: bool = False
 
     def __post_init__(self):
         if self.model_name:
@@ -110,6 +113,7 @@ class TaskCrullerPretrain(TaskTrain):
         if device.type != 'cuda':
             raise RuntimeError('TaskCrullerPretrain.train_setup: an MI355X (cuda/HIP device) is required; no CPU path exists')
         self.model.to(device)
+        self.model.set_train_dropout(bool(self.cfg.decoder_dropout), seed=42 + self.device_env.global_rank)   # random_seed(42, rank) convention
         opt = self.cfg.opt
         if opt.optimizer != 'adamw':
             raise NotImplementedError(f'optimizer {opt.optimizer!r}: only adamw (the reference default) is implemented')

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 C=pixparse_amd/csrc
 for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize $flags -c $C/attention.hip -o $C/attention.o || exit 1
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $C/gemm.o $C/gemm256.o $C/attention.o $C/rowops.o $C/loss_optim.o $C/swin.o $C/preprocess.o $C/skinny.o $C/attn_decode.o $C/capi.o || exit 1
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $(ls $C/*.o | tr "\n" " ") || exit 1
   echo "== $flags"
   python scripts/bench_kernels.py attn 2>&1 | grep attn
   python scripts/bench_kernels.py attn 2>&1 | grep attn

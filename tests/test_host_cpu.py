@@ -158,6 +158,19 @@ def test_no_cpu_fallback():
         TaskFactory.create_task('cruller_eval_docvqa', {}, DeviceEnv('cpu'), None)   # in the reference's registry, not built here
 
 
+def test_decoder_dropout_switch_cpu():
+    """dropout is an explicit opt-in (task cfg `decoder_dropout`, Cruller.set_train_dropout); decoders whose config also
+    drops attention probabilities / activations (bart-base) are refused rather than trained with a silently different regulariser"""
+    from pixparse_amd.models import Cruller, get_model_config
+    from pixparse_amd.task import TaskCrullerPretrainCfg
+    assert TaskCrullerPretrainCfg().decoder_dropout is False
+    small = Cruller(get_model_config('cruller_small'), vocab_size=515)        # swin_tiny + bart-base
+    with pytest.raises(NotImplementedError, match='attention / activation dropout'):
+        small.set_train_dropout(True)
+    small.set_train_dropout(False)
+    assert small._drop is None
+
+
 def test_task_surface_and_counters_cpu():
     """constructor side of the plug-in (runs without a GPU); train_setup refuses a CPU device loudly"""
     from types import SimpleNamespace

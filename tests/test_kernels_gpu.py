@@ -695,3 +695,38 @@ def test_gpu_image_preprocess(dev, H, W, C, Ho, Wo):
     ref = (ref - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)
     assert out.shape == (C, Ho, Wo)
     assert float((out.cpu() - ref).abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- dropout
+def test_dropout_kernels(dev):
+    """crl_dropout / crl_dropout_add / crl_dropout_mask: one stateless Philox mask per (seed, step, site) shared by all three, keep
+    rate 1 - p, exact arithmetic given the mask, different sites / steps / seeds decorrelated, p = 0 is the identity"""
+    from pixparse_amd import ops
+    n = 1 << 20
+    d = ops.DropSpec(0.1, 1234, 7)
+    keep = ops.dropout_mask(n, d, 3, dev).bool()
+    rate = float(keep.float().mean())
+    assert abs(rate - 0.9) < 3 * math.sqrt(0.09 / n) + 2e-5, rate            # binomial 3 sigma (+ the 16-bit threshold granularity)
+    assert torch.equal(keep, ops.dropout_mask(n, d, 3, dev).bool())           # pure function of its arguments
+    for other in (ops.dropout_mask(n, d, 4, dev), ops.dropout_mask(n, ops.DropSpec(0.1, 1234, 8), 3, dev), ops.dropout_mask(n, ops.DropSpec(0.1, 1235, 7), 3, dev)):
+        agree = float((other.bool() == keep).float().mean())
+        assert abs(agree - 0.82) < 5e-3, agree                                # independent masks agree with probability .81 + .01
+    x = rnd((n,), dev, 1.0, 1, BF16)
+    y = torch.empty_like(x)
+    ops.dropout(x, y, d, 3)
+    want = torch.where(keep, (x.float() * (1.0 / 0.9)).to(BF16), torch.zeros_like(x))
+    assert torch.equal(y, want)
+    xin = x.clone()
+    ops.dropout(xin, xin, d, 3)                                               # in place
+    assert torch.equal(xin, want)
+    f = rnd((n,), dev, 1.0, 2)
+    g, gb = torch.empty_like(f), torch.empty(n, dtype=BF16, device=dev)
+    ops.dropout(f, g, d, 3, y_bf16=gb)
+    wantf = torch.where(keep, f * (1.0 / 0.9), torch.zeros_like(f))
+    assert torch.allclose(g, wantf, rtol=1e-6, atol=0) and torch.equal(gb, g.to(BF16))
+    r = rnd((n,), dev, 1.0, 3)
+    out = torch.empty_like(r)
+    ops.dropout_add(x, r, out, d, 3)
+    assert torch.equal(out, r + want.float())
+    ops.dropout(x, y, ops.DropSpec(0.0, 1, 1), 0)
+    assert torch.equal(y, x)

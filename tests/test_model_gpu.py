@@ -134,6 +134,59 @@ def test_cruller_forward_backward_vs_oracle(dev, enc, img, fmt):
     assert abs(float(model.arena.g.norm()) - float(tot)) / float(tot) < 2e-2
 
 
+def test_decoder_dropout_matches_oracle_with_the_same_masks(dev):
+    """hidden-state dropout of the decoder (opt-in).  The oracle applies, at the reference's four dropout sites, the very
+    Philox masks the HIP kernels generate (crl_dropout_mask with the same seed / step / site): loss and every gradient then agree to
+    the tolerances of the dropout-free test; a second micro-step uses fresh masks; switching it off restores the dropout-free loss."""
+    from oracle import ref_cpu as R
+    from pixparse_amd import ops
+    from pixparse_amd.models import Cruller
+    _register_test_archs()
+    enc, img, fmt = 'vit_test', (37, 50), 'RGB'
+    L, layers, V, B = 24, 2, 515, 2
+    torch.manual_seed(0)
+    model = Cruller(_cfg(enc, img, fmt, layers, L), vocab_size=V)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.bias'):
+                p.normal_(0, 0.05)
+            elif p.dim() >= 2:
+                p.mul_(3.0)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith('lm_head.weight')}
+    spec = R.ModelSpec(enc, 'bart_test', layers, L, img, 1 if fmt == 'L' else 3, vocab=V)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=3, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    T, D = ti.shape[1], R.BART_ARCHS['bart_test']['d_model']
+    p_drop, seed = 0.1, 77
+    model.dec_arch = dict(model.dec_arch, dropout=p_drop)
+    model.to(dev)
+    model.arena.alloc_training_state()
+    plain = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    model.set_train_dropout(True, seed=seed)
+    losses = []
+    for step in range(2):
+        def drop(site, t, step=step):
+            keep = ops.dropout_mask(B * T * D, ops.DropSpec(p_drop, seed, step), site, dev).cpu().view(B, T, D).bool()
+            return torch.where(keep, (t.float() * (1.0 / (1.0 - p_drop))).to(t.dtype), torch.zeros_like(t))
+        op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        oloss = R.cruller_loss(op, spec, image, ti, tt, 'bf16', drop=drop)
+        oloss.backward()
+        model.arena.g.zero_()
+        loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+        model.backward()
+        losses.append(loss)
+        assert abs(loss - float(oloss)) / float(oloss) < 1e-3, (step, loss, float(oloss))
+        worst = sorted(((rel(model.arena.grad(k), op[k].grad), k) for k in params if not k.endswith('k_proj.bias')), reverse=True)
+        assert worst[0][0] < 5e-2, worst[:5]
+        tot = torch.sqrt(sum((op[k].grad.float() ** 2).sum() for k in params))
+        assert abs(float(model.arena.g.norm()) - float(tot)) / float(tot) < 2e-2
+    assert abs(losses[0] - plain) > 1e-4 * plain and abs(losses[0] - losses[1]) > 1e-5 * plain     # masks are live and change per micro-step
+    model.set_train_dropout(False)
+    assert float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev))) == plain
+    out = model(image.to(dev), ti.to(dev))        # forward() alone (eval / generation paths) never drops
+    assert out.logits.shape == (B, T, V)
+
+
 def test_task_train_steps_vs_oracle_trainer(dev):
     """3 optimiser updates with clip-norm + warmup cosine LR + grad accumulation 2: loss trajectory vs the oracle."""
     from oracle import ref_cpu as R
