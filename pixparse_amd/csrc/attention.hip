@@ -131,8 +131,14 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
     __builtin_amdgcn_s_setprio(PRIO_MFMA);     // waves with matrix work ready win the issue slot over waves in their softmax
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+#ifdef ATT_TIMING_HALF_LDS   // timing-only: half of the K / V fragment reads (wrong results) -- how LDS-read-bound is the forward?
+      const bf16x8 kfr = frag_row(kl, la, 0, ks);
+      s0 = mfma32(kfr, qf[ks], s0);
+      s1 = mfma32(kfr, qf[ks], s1);
+#else
       s0 = mfma32(frag_row(kl, la, 0, ks), qf[ks], s0);
       s1 = mfma32(frag_row(kl, la, 32, ks), qf[ks], s1);
+#endif
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- online softmax, query on the lane, this lane holds 2 x 16 of the tile's 64 keys
@@ -180,10 +186,18 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8 p0 = acc_frag(s0, s), p1 = acc_frag(s1, s);
+#ifdef ATT_TIMING_HALF_LDS
+      const bf16x8 v0f = frag_tr(vl, la, 16 * s, 0), v1f = frag_tr(vl, la, 16 * s, 1);
+      o0 = mfma32(v0f, p0, o0);
+      o1 = mfma32(v1f, p0, o1);
+      o0 = mfma32(v0f, p1, o0);
+      o1 = mfma32(v1f, p1, o1);
+#else
       o0 = mfma32(frag_tr(vl, la, 16 * s, 0), p0, o0);
       o1 = mfma32(frag_tr(vl, la, 16 * s, 1), p0, o1);
       o0 = mfma32(frag_tr(vl, la, 32 + 16 * s, 0), p1, o0);
       o1 = mfma32(frag_tr(vl, la, 32 + 16 * s, 1), p1, o1);
+#endif
 #if FWD_ONES
       o2 = mfma32(ones, p0, o2);
       o2 = mfma32(ones, p1, o2);
