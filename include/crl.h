@@ -222,7 +222,9 @@ int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, float grad_d
 /* p,m,v updated in place with g*state[1]; skipped entirely when state[2] != 0 (GradScaler.step);
  * p_bf16 (optional) receives the bf16 shadow of the new p; g is zeroed when zero_grad != 0.
  * step >= 1: bias corrections 1 - beta^step from the host's count; step == 0: from state[3], the device-side count of
- * steps actually taken (advanced by crl_grad_norm* only when the step is not skipped). */
+ * steps actually taken (advanced by crl_grad_norm* only when the step is not skipped); in that mode (8-float state) a
+ * positive state[6] clamps every unscaled gradient element to [-state[6], state[6]] first (torch clip_grad_value_,
+ * timm dispatch_clip_grad mode 'value'). */
 int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int step, const float* state, int zero_grad,
               void* stream);

@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   if (i >= n) return;
   const float coef = state ? state[1] : 1.f;
   const bool skip = state ? (state[2] != 0.f) : false;
+  // clip-by-value (timm dispatch_clip_grad mode 'value' = torch clip_grad_value_): |g| <= state[6] after unscaling; only with the
+  // 8-float device state of the task's optimiser (dev_step), 0 = off
+  const float cv = (dev_step && state[6] > 0.f) ? state[6] : INFINITY;
   if (dev_step && !skip) {               // bias corrections from the device-side count of steps taken (this one included)
     const float t = state[3];
     bc1 = 1.f - __builtin_amdgcn_exp2f(t * __builtin_amdgcn_logf(b1));
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gj = gp[j] * coef;
+        const float gj = fminf(fmaxf(gp[j] * coef, -cv), cv);
         if (wd != 0.f) pp[j] *= (1.f - lr * wd);
         mp[j] = b1 * mp[j] + (1.f - b1) * gj;
         vp[j] = b2 * vp[j] + (1.f - b2) * gj * gj;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   } else {
     for (size_t j = i; j < n; ++j) {
       if (!skip) {
-        const float gj = g[j] * coef;
+        const float gj = fminf(fmaxf(g[j] * coef, -cv), cv);
         if (wd != 0.f) p[j] *= (1.f - lr * wd);
         m[j] = b1 * m[j] + (1.f - b1) * gj;
         v[j] = b2 * v[j] + (1.f - b2) * gj * gj;

@@ -16,7 +16,7 @@ from .. import ops
 
 
 STATE_FLOATS = 8   # [0] grad norm, [1] clip * unscale coefficient, [2] found inf/nan, [3] optimiser steps TAKEN,
-                   # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6..7] unused   (include/crl.h)
+                   # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6] clip-by-value threshold (0 = off), [7] unused   (include/crl.h)
 
 
 class ArenaAdamW:
@@ -30,6 +30,11 @@ class ArenaAdamW:
         arena.alloc_training_state()
         self.state = torch.zeros(STATE_FLOATS, dtype=torch.float32, device=arena.p.device)
         self.state[4] = 1.0   # no loss scaling until a LossScaler attaches
+
+    def set_clip_value(self, value: Optional[float]):
+        """timm dispatch_clip_grad mode 'value' (torch clip_grad_value_): clamp every unscaled gradient element to [-value, value]
+        inside the AdamW launch; None / 0 switches it off"""
+        self.state[6] = float(value or 0.0)
 
     @property
     def step_count(self) -> int:

@@ -121,13 +121,15 @@ class TaskCrullerPretrain(TaskTrain):
             raise NotImplementedError(f'scheduler {opt.scheduler!r}: only cosine is implemented')
         if opt.layer_decay is not None or opt.momentum is not None:
             raise NotImplementedError('layer_decay / momentum are not supported by the fused AdamW path')
-        if opt.clip_grad_value is not None and (opt.clip_grad_mode or 'norm') != 'norm':
-            raise NotImplementedError(f'clip_grad_mode {opt.clip_grad_mode!r}: only "norm" is implemented')
+        self.clip_mode = (opt.clip_grad_mode or 'norm') if opt.clip_grad_value is not None else None    # timm dispatch_clip_grad (ref :270-278)
+        if self.clip_mode not in (None, 'norm', 'value'):
+            raise NotImplementedError(f'clip_grad_mode {opt.clip_grad_mode!r}: "norm" and "value" are implemented (not "agc")')
         kw = {}
         if opt.betas is not None:
             kw['betas'] = tuple(opt.betas)
         # NOTE weight_decay is not forwarded, exactly like the reference (:196-203) -> 0
         self.optimizer = ArenaAdamW(self.model.arena, lr=opt.learning_rate, eps=opt.eps, weight_decay=0.0, **kw)
+        self.optimizer.set_clip_value(opt.clip_grad_value if self.clip_mode == 'value' else None)
         self.model._ensure_engines()
         self.reducer = BucketedGradReducer(self.model.arena, self.device_env.world_size,
                                            active=getattr(self.device_env, 'distributed', self.device_env.world_size > 1))
@@ -168,7 +170,8 @@ class TaskCrullerPretrain(TaskTrain):
         if need_update:
             opt = self.cfg.opt
             # NativeScaler.__call__ (ref :259-278): unscale_ -> clip_grad_norm_ -> scaler.step (skips on inf/nan) -> scaler.update
-            self.optimizer.step(clip_norm=opt.clip_grad_value, zero_grad=True, scaler=self.scaler, grad_divisor=self.reducer.grad_divisor())
+            self.optimizer.step(clip_norm=opt.clip_grad_value if self.clip_mode == 'norm' else None, zero_grad=True, scaler=self.scaler,
+                                grad_divisor=self.reducer.grad_divisor())
             self.model.refresh_shadows(full=False)
 
     log_phase_name = 'train'

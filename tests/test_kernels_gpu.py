@@ -638,6 +638,42 @@ def test_adamw_with_device_gradscaler_vs_torch(dev):
     assert sc.state_dict()['_growth_tracker'] == 0 and opt.state_dict()['step'] == 5
 
 
+def test_adamw_clip_by_value_vs_torch(dev):
+    """timm dispatch_clip_grad mode 'value' (ref task_cruller_pretrain.py:270-278) = torch clip_grad_value_ on the UNSCALED gradient,
+    applied inside the AdamW launch (state[6]); with a loss scale of 256 on the stored gradients"""
+    from pixparse_amd.framework.optim import ArenaAdamW, LossScaler
+    from pixparse_amd.layers.arena import ParamArena
+    torch.manual_seed(1)
+    n = 2 * 4096 + 64
+    arena = ParamArena()
+    arena.add('w', (n,))
+    arena.materialize(dev)
+    arena.p.copy_(torch.randn(n, device=dev) * 0.1)
+    lr, betas, eps, cv = 1e-2, (0.9, 0.98), 1e-6, 0.3
+    opt = ArenaAdamW(arena, lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+    arena.alloc_shadow()
+    opt.set_clip_value(cv)
+    sc = LossScaler(init_scale=256.0, growth_interval=1000).attach(opt.state)
+    pr = torch.nn.Parameter(arena.p.clone())
+    topt = torch.optim.AdamW([pr], lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+    for i in range(3):
+        g = torch.randn(n, device=dev) * (0.2 + 0.3 * i)
+        assert float((g.abs() > cv).float().mean()) > 0.05       # the clamp is live
+        arena.g.copy_(g * 256.0)
+        opt.step(clip_norm=None, zero_grad=True, scaler=sc, grad_divisor=1.0)
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_value_([pr], cv)
+        topt.step()
+        close(arena.p, pr.detach(), 2e-6, 1e-7, f'clip-by-value update {i}')
+    opt.set_clip_value(None)
+    g = torch.randn(n, device=dev)
+    arena.g.copy_(g * 256.0)
+    opt.step(clip_norm=None, zero_grad=True, scaler=sc, grad_divisor=1.0)
+    pr.grad = g.clone()
+    topt.step()
+    close(arena.p, pr.detach(), 2e-6, 1e-7, 'clamp off again')
+
+
 def test_out_of_range_ids_and_targets_do_not_touch_memory(dev):
     """torch raises a device assert for an out-of-vocabulary id / target; here the damage is contained and LOUD:
     embedding rows and the loss turn NaN, the scatter skips the row, nothing outside the tables is read or written"""
