@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
   const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
 
   const int q0 = qt * 128 + wave * 32;
+  const bool wave_live = q0 < a.Nq;    // wave-uniform (N = 6189: the last of 49 query tiles has 45 valid rows -> two idle waves, -1 % of the launch)
   const int qrow = min(q0 + qi, a.Nq - 1);
   bf16x8 qf[4];
 #pragma unroll
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nt) stage(BUFI ^ 1, kt + 1);
+    if (!wave_live) return;     // all 32 queries of this wave lie past Nq (ragged last tile): it only stages and keeps the barriers
     const char* kl = smem + BUFI * 16384;
     const char* vl = kl + 8192;
     const int k0 = kt * 64;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
   const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs);
 
   const int key0 = ktile * 128 + wave * 32;
+  const bool wave_live = key0 < a.Nk;
   const int kabs = key0 + ki;
   const int krow = min(kabs, a.Nk - 1);
   bf16x8 kf[4], vf[4];
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nqt64) stage(BUFI ^ 1, t + 1);
+    if (!wave_live) return;     // all 32 keys of this wave lie past Nk
     const char* ql = smem + BUFI * BUF;
     const char* dol = ql + 8192;
     const float* lse_s = reinterpret_cast<const float*>(ql + 16384);
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
 
   const int q0 = qt * 128 + wave * 32;
+  const bool wave_live = q0 < a.Nq;
   const int qabs = q0 + qi;
   const int qrow = min(qabs, a.Nq - 1);
   bf16x8 qf[4], dof[4];
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nt) stage(BUFI ^ 1, kt + 1);
+    if (!wave_live) return;     // all 32 queries of this wave lie past Nq
     const char* kl = smem + BUFI * 16384;
     const char* vl = kl + 8192;
     const int k0 = kt * 64;
