@@ -196,3 +196,35 @@ def test_cfg3_step_is_deterministic_and_starts_at_expected_loss(dev):
     # tied LM head on unit-variance LayerNorm outputs: logits ~ N(0, (0.02 sqrt(1024))^2) -> E[loss] = ln V + sigma^2 / 2
     expect = math.log(VOCAB) + 0.5 * (0.02 * math.sqrt(1024)) ** 2
     assert abs(a[0][0] - expect) < 0.05 and all(math.isfinite(v) for pair in a for v in pair), (a, expect)
+
+
+def test_cfg3_batch8_learns_a_fixed_batch(dev):
+    """size-independent property at the headline configuration (cfg-3, batch 8, the bench's step): sixteen updates on ONE fixed batch
+    (AdamW 1e-4, clip-norm 1, no warm-up) drive the loss from ln V + sigma^2/2 down by more than 1.5 nats, every loss and gradient norm
+    finite -- forward, backward, clipping, optimiser, bf16 shadow refresh and the schedule work together at full size (measured: 11.05 ->
+    8.48)"""
+    from pixparse_amd.data import synthetic_batch
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.models import get_model_config
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    mc = get_model_config('cruller_large_1280x960')
+    mc.image_encoder.pretrained = False
+    mc.text_decoder.pretrained = False
+    cfg = TaskCrullerPretrainCfg(num_intervals=1, num_warmup_intervals=0, eval_frequency=10 ** 9, dtype='bfloat16',
+                                 opt=OptimizationCfg(learning_rate=1e-4, clip_grad_value=1.0, clip_grad_mode='norm'), model=mc)
+    torch.manual_seed(0)
+    task = TaskCrullerPretrain(cfg, DeviceEnv())
+    task.train_setup(num_batches_per_interval=1000)
+    task.train_interval_start()
+    m = task.model
+    sample = synthetic_batch(8, m.in_chans, m.img_size, m.max_length, task.vocab_size, seed=5)
+    hist = []
+    for _ in range(16):
+        task.train_step(sample)
+        hist.append((float(task.last_loss), float(task.optimizer.grad_norm())))
+    del task
+    torch.cuda.empty_cache()
+    assert all(math.isfinite(a) and math.isfinite(b) for a, b in hist), hist
+    expect = math.log(VOCAB) + 0.5 * (0.02 * math.sqrt(1024)) ** 2
+    assert abs(hist[0][0] - expect) < 0.05, (hist[0], expect)
+    assert hist[-1][0] < hist[0][0] - 1.5 and min(h[0] for h in hist[8:]) == hist[-1][0], hist
