@@ -117,8 +117,8 @@ int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, 
 int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
                  float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
-/* delta: scratch of 2*B*H*Nq fp32 (row constants -delta and -lse/scale that seed the MFMA accumulators).
- * dq/dk/dv strides as q/k/v. */
+/* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators: the dQ
+ * pass, which runs first, computes them from the dO / O rows it holds and stores them for the dK/dV pass).  dq/dk/dv strides as q/k/v. */
 int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
