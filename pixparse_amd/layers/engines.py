@@ -584,8 +584,8 @@ class BartEngine(_Base):
         return logits
 
     def backward(self, dlogits: torch.Tensor, enc16: torch.Tensor, denc: torch.Tensor, on_layer_done=None):
-        """dlogits bf16 [M, Vp] (pad columns zero); accumulates the encoder-output gradient into denc (fp32 [B*S, D],
-        must be zeroed by the caller)."""
+        """dlogits bf16 [M, Vp] (pad columns zero); writes the encoder-output gradient to denc (fp32 [B*S, D]; overwritten, not
+        accumulated: no zero fill needed)."""
         dp, D, F_, H = self.DP, self.D, self.F, self.heads
         B, T, S = self.B, self.T, self.S
         M, Me = B * T, B * S
@@ -607,6 +607,8 @@ class BartEngine(_Base):
         dkv2 = self.buf('dkv2', (Me, 2 * D), BF16)
         dqkv = self.buf('dqkv', (M, 3 * D), BF16)
         delta = self.buf('delta', (2, B, H, T), F32)
+        if self.L == 0:
+            denc.zero_()
         for i in reversed(range(self.L)):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             g = lambda n: Tb[tg + k + n]
@@ -625,7 +627,8 @@ class BartEngine(_Base):
                          dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False)
             ops.linear_dgrad(dq2, self.W(lp + 'encoder_attn.q_proj.weight'), dhb)
             self.lin_wgrad(lp + 'encoder_attn.q_proj', dq2, g('.ln1.y16'))
-            ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32_ACC)
+            # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
+            ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32 if i == self.L - 1 else EPI_F32_ACC)
             ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
             ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))

@@ -373,8 +373,7 @@ class Cruller(nn.Module):
         enc, dec, bufs = self._ensure_engines()
         assert self.arena.g is not None, 'call alloc_training_state() (train_setup) before backward'
         S = enc.out_tokens()
-        denc = bufs.get('denc', (dec.B * S, dec.D), torch.float32)
-        denc.zero_()
+        denc = bufs.get('denc', (dec.B * S, dec.D), torch.float32)     # written (not accumulated) by the decoder's last layer first
         dec.backward(bufs.t['dec.logits'], bufs.t[enc.tag + '.norm.y16'], denc, on_ready)
         enc.backward(denc, on_ready)
 
