@@ -103,16 +103,29 @@ def collect_live_profile(steps):
     table = {}
     for i, name in enumerate(KERNEL_NAMES):
         if launches[i]:
+            tf = work[i] / (ms[i] * 1e-3) / 1e12
             table[name] = {'launches_per_step': round(launches[i] / steps, 1), 'ms_per_launch': round(ms[i] / launches[i], 4),
-                           'ms_per_step': round(ms[i] / steps, 2), 'tflops': round(work[i] / (ms[i] * 1e-3) / 1e12, 1)}
+                           'ms_per_step': round(ms[i] / steps, 2), 'tflops': round(tf, 1), 'frac': round(tf / PEAK_BF16_TFLOPS, 4)}
     if not table:
         return None
     i = max(range(n), key=lambda j: ms[j])
     achieved = work[i] / (ms[i] * 1e-3) / 1e12
+    # the WHOLE attention backward (every backward launch of the step, both passes or the fused pass): algorithmic FLOPs = 2 x forward
+    # (dV, dP, dK, dQ; recomputed products not credited) over the summed duration
+    bwd = [j for j, nm in enumerate(KERNEL_NAMES) if 'bwd' in nm and launches[j]]
+    bwd_ms, bwd_work = sum(ms[j] for j in bwd), sum(work[j] for j in bwd)
+    fwd = [j for j, nm in enumerate(KERNEL_NAMES) if 'fwd' in nm and launches[j]]
+    att = {'attention_bwd_total': {'ms_per_step': round(bwd_ms / steps, 2), 'tflops': round(bwd_work / (bwd_ms * 1e-3) / 1e12, 1),
+                                   'frac': round(bwd_work / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   'what': 'all attention-backward launches of the step; algorithmic FLOPs = 8 Nq Nk 64 per head (2 x forward)'}} if bwd_ms else {}
+    if fwd:
+        fms, fw = sum(ms[j] for j in fwd), sum(work[j] for j in fwd)
+        att['attention_fwd_total'] = {'ms_per_step': round(fms / steps, 2), 'tflops': round(fw / (fms * 1e-3) / 1e12, 1),
+                                      'frac': round(fw / (fms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
     return {'bound': 'mfma', 'kernel': KERNEL_NAMES[i], 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'ms_per_launch': round(ms[i] / launches[i], 4),
             'launches_timed': int(launches[i]), 'measured': 'HIP events around every launch inside the timed steps (crl_prof_begin/end)',
-            'kernels': table}
+            'kernels': table, **att}
 
 
 def measured_gemm_peak(dev, launches=200, reps=2):
@@ -130,15 +143,30 @@ def measured_gemm_peak(dev, launches=200, reps=2):
     return best
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_traffic.py -> profiles/)"""
-    path = os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')
-    if not os.path.exists(path):
+KERNEL_SOURCE = 'attention.hip'     # where every kernel of KERNEL_NAMES lives
+
+
+def pmc_traffic(kernel, grid_threads=None):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_traffic.py -> profiles/), for the launch geometry
+    `grid_threads` when the file splits the symbol by shape.  None when the kernel's source has changed since the passes were taken
+    (the file records the sha1 of every kernel source): a stale figure is worse than none."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
         return None, None
-    with open(path) as f:
+    with open(files[-1]) as f:
         t = json.load(f)
+    src = os.path.join(ROOT, 'pixparse_amd', 'csrc', KERNEL_SOURCE)
+    want = t.get('csrc_sha1', {}).get(KERNEL_SOURCE)
+    if want is None or not os.path.exists(src) or hashlib.sha1(open(src, 'rb').read()).hexdigest() != want:
+        return None, f'{os.path.basename(files[-1])} was measured on an older {KERNEL_SOURCE}: omitted'
     k = t.get('kernels', {}).get(kernel)
-    return (k['hbm_bytes_per_launch'], t.get('source')) if k else (None, None)
+    if not k:
+        return None, None
+    if grid_threads is not None and str(grid_threads) in k.get('by_grid', {}):
+        k = k['by_grid'][str(grid_threads)]
+    return k['hbm_bytes_per_launch'], t.get('source')
 
 
 def dominant_kernel_roofline(task, B):
@@ -236,6 +264,11 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--host-inputs', action='store_true', help='feed pinned host batches (PCIe-inclusive rate) instead of HBM-resident ones')
     ap.add_argument('--no-host-leg', action='store_true', help='skip the second timed region with pinned host batches')
+    ap.add_argument('--no-peak', action='store_true', help='skip the standalone-kernel and 8192^3 GEMM legs (clean rocprofv3 traces of the step)')
+    ap.add_argument('--occupy-cus', type=int, default=0, help='measurement aid: N CUs held by a sleeping side-stream kernel during the timed '
+                    'steps (single-GPU stand-in for the CUs RCCL takes in a data-parallel run); the line says so in `disturbance`')
+    ap.add_argument('--gemm-schedule', choices=['dynamic', 'static'], default='dynamic', help='tile schedule of the persistent GEMMs (A/B)')
+    ap.add_argument('--reserved-cus', type=int, default=0, help='persistent GEMMs launch on 256 - N CUs (A/B with --occupy-cus)')
     args = ap.parse_args()
 
     from pixparse_amd.data import SyntheticLoaderBundle
@@ -269,10 +302,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    from pixparse_amd import hip, ops
+    import contextlib
+    ops.gemm_set_schedule(args.gemm_schedule == 'dynamic')
+    ops.gemm_set_reserved_cus(args.reserved_cus)
     for _ in range(args.warmup):
         task.train_step(next(it))
     sync()
-    from pixparse_amd import hip
+    disturb = ops.OccupyCUs(args.occupy_cus, max_seconds=100.0) if args.occupy_cus > 0 else contextlib.nullcontext()
+    disturb.__enter__()
     live = env.global_rank == 0 and not args.no_roofline
     if live:   # HIP events around every attention-kernel launch of the timed steps, on the launch stream (include/crl.h)
         hip.call('crl_prof_begin', 256 * args.steps)
@@ -281,6 +319,8 @@ def main():
         task.train_step(next(it))
     sync()
     dt = time.perf_counter() - t0
+    disturb.__exit__(None, None, None)
+    loss = float(task.last_loss)      # the loss of the timed region (the host-input leg below runs further steps)
     live_prof = collect_live_profile(args.steps) if live else None
     if env.distributed:
         tt = torch.tensor([dt], device=env.device, dtype=torch.float64)
@@ -306,7 +346,6 @@ def main():
             hdt = float(tt)
         host = {'value': round(hs * args.batch * env.world_size / hdt, 4), 'unit': 'docs/s', 'ms_per_step': round(hdt / hs * 1e3, 2), 'steps': hs,
                 'what': 'same step fed pinned HOST batches (H2D of the image batch inside train_step, the reference boundary); not `value`'}
-    loss = float(task.last_loss)
     docs = args.steps * args.batch * env.world_size
     value = docs / dt
     f_fwd, S = flops_per_doc(task)
@@ -330,14 +369,31 @@ def main():
     }
     if host is not None:
         out['host_inputs'] = host
+    if args.occupy_cus or args.reserved_cus or args.gemm_schedule != 'dynamic':
+        out['disturbance'] = {'occupied_cus': args.occupy_cus, 'reserved_cus': args.reserved_cus, 'gemm_schedule': args.gemm_schedule,
+                              'what': 'A/B run for the multi-GPU CU-contention experiment (DESIGN.md (e)); not a headline number'}
     if env.global_rank == 0:
         if live_prof is not None:
             out['roofline'] = live_prof
-            traffic, src = pmc_traffic(live_prof['kernel'])
+            # the dominant symbol also serves the decoder's cross-attention; traffic is quoted for the encoder-shape launches only
+            # (grid = tiles x B x H workgroups of 256 threads) next to that shape's algorithmic bytes (each operand once)
+            grid, algo = None, None
+            if m.enc_kind == 'vit' and live_prof['kernel'].endswith('<false>'):
+                enc_ = m._engines[0]
+                tiles = (enc_.N + 127) // 128
+                grid = tiles * args.batch * enc_.heads * 256
+                n_operands = {'attn_fwd_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6}[live_prof['kernel']]
+                algo = n_operands * args.batch * enc_.N * enc_.D * 2
+            traffic, src = pmc_traffic(live_prof['kernel'], grid)
             if traffic is not None:
                 live_prof['traffic'] = traffic
                 live_prof['traffic_source'] = src
-            if env.world_size == 1:
+                if algo:
+                    live_prof['traffic_algorithmic'] = algo
+                    live_prof['traffic_shape'] = f'encoder self-attention launches (N = {enc_.N}, grid {grid} threads)'
+            elif src:
+                live_prof['traffic_note'] = src
+            if env.world_size == 1 and not args.no_peak:
                 try:
                     out['roofline']['standalone'] = dominant_kernel_roofline(task, args.batch)
                 except Exception as e:  # never lose the headline number to the microbench

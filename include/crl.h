@@ -55,6 +55,17 @@ size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t
  * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent
  * workgroups per CU: epilogues overlap main loops) for the NT / NN layouts whenever legal. */
 int crl_gemm_set_policy(int policy);
+/* Data-parallel runs share the GPU with RCCL's all-reduce kernels (ref: DistributedDataParallel's bucket all-reduces,
+ * task/task_cruller_pretrain.py:181-189, overlapping backward).  The 256-row kernels are persistent: one (two) resident
+ * workgroup(s) per CU.
+ * crl_gemm_set_schedule(1) (default): the resident workgroups PULL output tiles from per-launch device ticket counters (one
+ *   list per XCD, stealing when a list is empty), so a launch that finds n CUs occupied by another kernel takes
+ *   ceil(tiles / (256 - n)) tile times; 0 = the static walk (workgroup b owns tiles b, b + grid, ...: every workgroup that
+ *   cannot be placed at once delays the launch by its whole list).  Results are bit-identical either way.
+ * crl_gemm_set_reserved_cus(n), 0 <= n <= 224: launch on 256 - n CUs and re-plan the wave-quantisation split for that
+ *   width (set by the gradient reducer while buckets are in flight when PIXPARSE_AMD_RCCL_CUS asks for it; default 0). */
+int crl_gemm_set_schedule(int dynamic);
+int crl_gemm_set_reserved_cus(int n);
 int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
@@ -134,6 +145,11 @@ int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
 #define CRL_K_ATTN_BWD_DKDV 2   /* attn_bwd_dkdv_kernel<false>, + 1 = <true> */
 #define CRL_K_ATTN_BWD_DQ 4     /* attn_bwd_dq_kernel<false>,   + 1 = <true> */
 #define CRL_K_COUNT 6
+/* Measurement aid (never on the product path): n_cus workgroups that each take a whole CU (all 160 KiB of its LDS) and sleep
+ * until max_seconds (<= 120) have passed or *stop_flag (optional; device-visible, e.g. pinned host memory) becomes non-zero.
+ * Stands in, on one GPU, for the CUs RCCL's all-reduce kernels hold while gradient buckets are in flight (bench.py
+ * --occupy-cus). Launch it on a stream of its own BEFORE the work it should disturb. */
+int crl_debug_occupy_cus(int n_cus, double max_seconds, const int* stop_flag, void* stream);
 int crl_prof_begin(int capacity);
 int crl_prof_end(int n_ids, int* launches, double* ms, double* work);
 

@@ -207,6 +207,35 @@ int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
 int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t s);
 
+// ---- launch geometry of the persistent kernels + the ticket-counter pool of the dynamic tile scheduler (gemm_common.h) ----
+#include <atomic>
+static constexpr int CHIP_CUS = 256;
+static int g_reserved_cus = 0;     // CUs left to other kernels (RCCL) by the persistent launches
+static int g_dynamic = 1;          // 1 = resident workgroups pull tiles from ticket counters, 0 = static walk b, b + grid, ...
+__device__ uint32_t g_sched_state[gemmc::CRL_SCHED_SLOTS * gemmc::CRL_SCHED_WORDS];   // zero at module load; every launch leaves its slot zeroed
+int crl_gemm_cus() { return CHIP_CUS - g_reserved_cus; }
+bool crl_gemm_dynamic() { return g_dynamic != 0; }
+uint32_t* crl_sched_slot() {
+  static uint32_t* base = nullptr;
+  static std::atomic<unsigned> seq{0};
+  if (!base) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_state)) != hipSuccess || !p) { crl_set_error("crl_gemm_bf16: no scheduler state"); return nullptr; }
+    base = (uint32_t*)p;
+  }
+  return base + (size_t)(seq.fetch_add(1) % gemmc::CRL_SCHED_SLOTS) * gemmc::CRL_SCHED_WORDS;
+}
+extern "C" int crl_gemm_set_reserved_cus(int n) {
+  if (n < 0 || n > CHIP_CUS - 32) { crl_set_error("crl_gemm_set_reserved_cus: %d is outside [0, %d]", n, CHIP_CUS - 32); return -1; }
+  g_reserved_cus = n;
+  return 0;
+}
+extern "C" int crl_gemm_set_schedule(int dynamic) {
+  if (dynamic != 0 && dynamic != 1) { crl_set_error("crl_gemm_set_schedule: 0 = static, 1 = dynamic"); return -1; }
+  g_dynamic = dynamic;
+  return 0;
+}
+
 // Kernel / split-K plan.  big = 256x256 8-phase kernel (one workgroup per CU) when it fills the chip, else the
 // 128x128 kernel.  The wgrad layout (few output tiles, very long contraction) cuts the contraction into nsplit
 // chunks: partial tiles go to fp32 slabs in the caller's scratch, then one deterministic reduce pass.
@@ -232,10 +261,11 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
     return ns < 1 ? 1 : ns;
   };
   if (k64 && g_policy != 1 && ((M >= 256 && N >= 256) || g_policy == 2)) {
-    const int ns = split_for(t256, 256);   // one workgroup per CU: aim at one full wave of split tiles
-    if (t256 * ns >= 192 || g_policy == 2) { p.big = true; p.nsplit = ns; }
+    const int ncu = crl_gemm_cus();
+    const int ns = split_for(t256, ncu);   // one workgroup per CU: aim at one full wave of split tiles
+    if (t256 * ns >= (3 * ncu) / 4 || g_policy == 2) { p.big = true; p.nsplit = ns; }
   }
-  if (!p.big) p.nsplit = k64 ? split_for(t128, 768) : 1;
+  if (!p.big) p.nsplit = k64 ? split_for(t128, 3 * crl_gemm_cus()) : 1;
   p.chunk = (nk + p.nsplit - 1) / p.nsplit;
   p.nsplit = (int)((nk + p.chunk - 1) / p.chunk);
   return p;
@@ -245,15 +275,19 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
 // trimming a few row tiles lands on a whole number of waves, the big kernel takes the first 256*R rows and the remaining rows
 // (< 9 row tiles) go to the 128x128 kernel, whose small tiles pack 2 per CU.  Returns R, or -1 for "no split".
 static int64_t quant_rows(int layout, int64_t M, int64_t N) {
-  const int64_t ntn = (N + 255) / 256, rmax = M / 256;
+  const int64_t ntn = (N + 255) / 256, rmax = M / 256, ncu = crl_gemm_cus();
+  const int64_t wmax = (((M + 255) / 256) * ntn + ncu - 1) / ncu;   // whole tile times of the unsplit launch
   int64_t best_r = -1;
-  double best_cost = (double)((((M + 255) / 256) * ntn + 255) / 256);   // in units of one 256-tile time
+  double best_cost = (double)wmax;                                    // in units of one 256-tile time
   if (layout == CRL_TN) return -1;
-  for (int64_t r = rmax; r >= 1 && r >= rmax - 8; --r) {
+  // candidates: the most row tiles that fit w whole rounds of the resident workgroups (with reserved CUs a round is shorter, so the
+  // cut moves: 49 512 x 1024 on 224 CUs = 168 row tiles in 3 rounds + 25.4 row tiles for the small kernel)
+  for (int64_t w = wmax; w >= 1 && w >= wmax - 2; --w) {
+    const int64_t r = (w * ncu) / ntn < rmax ? (w * ncu) / ntn : rmax;
     const int64_t rem = M - 256 * r;
-    if (rem <= 0) continue;
-    const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 511) / 512);
-    const double cost = (double)((r * ntn + 255) / 256) + small;
+    if (r < 1 || rem <= 0) continue;
+    const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 2 * ncu - 1) / (2 * ncu));
+    const double cost = (double)((r * ntn + ncu - 1) / ncu) + small;
     if (cost < best_cost - 0.2) { best_cost = cost; best_r = r; }
   }
   return best_r;
@@ -331,6 +365,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc; a.ldaux = (int)ldaux; a.ldr = (int)ldr;
   a.a_bytes = (uint32_t)ab; a.b_bytes = (uint32_t)bb;
+  a.sched = nullptr;
   a.ntm = (int)((M + BM - 1) / BM); a.ntn = (int)((N + BN - 1) / BN);
   hipStream_t s = as_stream(stream);
   Plan p = plan_gemm(layout, epilogue, M, N, K, ws != nullptr);

@@ -54,7 +54,27 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
 #define G_PERSIST 1   // one workgroup per CU walks the tile list; the next tile's first K tiles are in flight during the epilogue (same-box A/B: +3..5 % on the K=1024 NT shapes, +0.1 % on the whole cfg-3 step)
 #endif
   const int ntiles = g.ntm * g.ntn;
-  int logical = blockIdx.x;           // position in the launch order; a persistent workgroup advances it by gridDim.x
+  // position in the XCD-aware tile order.  Static schedule (split-K launches, launches with a tile or less per workgroup): blockIdx.x,
+  // advanced by gridDim.x.  Dynamic schedule (g.sched, every persistent launch): pulled from the ticket counters by lane 0 of wave 0
+  // and handed to the other waves through s_next -- the pull for the NEXT tile is issued when a tile starts and read after its K loop.
+  __shared__ int s_next, s_list;      // s_list: the list (XCD) this workgroup pulls from (kept out of the registers: the epilogues are full)
+  const bool dyn = g.sched != nullptr;
+  uint32_t ticket = 0;
+  int logical = blockIdx.x;
+  if (dyn) {
+    if (wave == 0 && lane == 0) {
+      int my_list = sched_xcd();
+      ticket = sched_pull(g.sched + my_list);
+      s_next = sched_resolve(g.sched, my_list, ticket, ntiles);
+      s_list = my_list;
+    }
+    __syncthreads();
+    logical = __builtin_amdgcn_readfirstlane(s_next);
+    if (logical < 0) {                // started after the resident workgroups had emptied the queue
+      if (tid == 0) sched_leave(g.sched, gridDim.x);
+      return;
+    }
+  }
   int m0, n0;
   auto set_tile = [&](int l) {
     const int t = xcd_remap(l, ntiles);
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetched half-tiles AND the previous epilogue's stores
   BAR();
   TM(1);
+  if (dyn && wave == 0 && lane == 0) ticket = sched_pull(g.sched + s_list);   // the answer arrives under the K loop
   // stagger (guide §5 template): the wr==1 waves run one barrier behind, so on every SIMD one wave is in its
   // MFMA cluster while its partner (the wave 4 slots away shares the SIMD) issues LDS reads and DMA.
 #ifndef G_STAGGER
@@ -231,7 +252,15 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
     tile_phases(std::integral_constant<int, 1>{}, te + 2, te + 3);
   }
   TM(2);
-  if (G_STAGGER && wr == 0) BAR();
+  if (dyn && wave == 0) {             // publish the next tile before the barrier that closes the K loop for every wave
+    if (lane == 0) {
+      int my_list = s_list;
+      s_next = sched_resolve(g.sched, my_list, ticket, ntiles);
+      s_list = my_list;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if ((G_STAGGER && wr == 0) || (dyn && !G_STAGGER)) BAR();
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
   TM(3);
 
@@ -240,8 +269,8 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   // ~80 VGPRs across the loop and push the accumulators into scratch)
   int lane_e = lane, m0e = m0, n0e = n0;
   asm volatile("" : "+v"(lane_e), "+s"(m0e), "+s"(n0e));
-  const int next_logical = logical + (int)gridDim.x;
-  const bool has_next = G_PERSIST && gridDim.y == 1 && next_logical < ntiles;
+  const int next_logical = dyn ? __builtin_amdgcn_readfirstlane(s_next) : logical + (int)gridDim.x;
+  const bool has_next = G_PERSIST && gridDim.y == 1 && next_logical >= 0 && next_logical < ntiles;
   if (has_next) {   // LDS is idle from here on: stage the next tile's first six half-tiles under the epilogue
     set_tile(next_logical);
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
@@ -255,6 +284,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   logical = next_logical;
   first_tile = false;
   }
+  if (dyn && tid == 0) sched_leave(g.sched, gridDim.x);
 }
 
 template <int LAYOUT, int EPI>
@@ -267,13 +297,19 @@ int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
     configured = true;
   }
   int grid_x = a.ntm * a.ntn;
+  GemmArgs b = a;
+  b.sched = nullptr;
 #if G_PERSIST
-  if (nsplit == 1 && grid_x > 256) grid_x = 256;   // one resident workgroup per CU walks the tiles
+  const int ncu = crl_gemm_cus();
+  if (nsplit == 1 && grid_x > ncu) {   // one resident workgroup per CU pulls tiles from the launch's ticket counters
+    grid_x = ncu;
+    if (crl_gemm_dynamic()) { b.sched = crl_sched_slot(); if (!b.sched) return -2; }
+  }
 #endif
 #ifdef G_GRID_CAP
   if (nsplit == 1 && grid_x > G_GRID_CAP) grid_x = G_GRID_CAP;   // debug: fewer CUs busy (is a phase chip-bound or CU-bound?)
 #endif
-  gemm256_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T256, 131072, s>>>(a);
+  gemm256_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T256, 131072, s>>>(b);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(256)");
   return 0;
 }

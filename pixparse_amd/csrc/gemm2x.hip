@@ -102,8 +102,26 @@ __global__ __launch_bounds__(T2, 2) void gemm2x_kernel(const GemmArgs g) {
     }
   }
 
+  // Tile order: static walk (blockIdx.x, + gridDim.x) or, with g.sched, tickets pulled by lane 0 of wave 0 (gemm_common.h TileSched).
+  // All 80 KiB of LDS belong to the ring (two workgroups per CU), so the mailbox that hands a pulled position to the other waves is the
+  // first word of the ring, used only between tiles when no DMA is in flight and no fragment read is pending.
+  const bool dyn = g.sched != nullptr;
+  int* const mailbox = reinterpret_cast<int*>(smem);
+  int my_list = 0;
+  uint32_t ticket = 0;
+  int logical = blockIdx.x;
+  if (dyn) {
+    if (wave == 0 && lane == 0) {
+      my_list = sched_xcd();
+      ticket = sched_pull(g.sched + my_list);
+      *mailbox = sched_resolve(g.sched, my_list, ticket, ntiles);
+    }
+    __syncthreads();
+    logical = __builtin_amdgcn_readfirstlane(*mailbox);
+    __syncthreads();
+  }
   f32x4 acc[2][2][4][2];
-  for (int logical = blockIdx.x; logical < ntiles; logical += (int)gridDim.x) {   // persistent: two resident workgroups per CU walk the tiles
+  while (logical >= 0 && logical < ntiles) {   // persistent: two resident workgroups per CU walk the tiles
   {
     const int t_id = xcd_remap(logical, ntiles);
     m0 = (t_id / g.ntn) * 256; n0 = (t_id % g.ntn) * 128;
@@ -154,6 +172,7 @@ __global__ __launch_bounds__(T2, 2) void gemm2x_kernel(const GemmArgs g) {
   issue(0, 0, 0); issue(1, 0, UNIT); issue(2, 0, 2 * UNIT); issue(0, 1, 3 * UNIT);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   BAR();
+  if (dyn && wave == 0 && lane == 0) ticket = sched_pull(g.sched + my_list);   // next tile: the answer arrives under the K loop
 
 #pragma nounroll
   for (int t = 0; t < nk; ++t) {
@@ -186,12 +205,21 @@ __global__ __launch_bounds__(T2, 2) void gemm2x_kernel(const GemmArgs g) {
     sA0 = adv(sA0); sB = adv(sB); sA1 = adv(sA1);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // no DMA may outlive the workgroup; MFMA results settle before VALU reads
+  int next_logical = logical + (int)gridDim.x;
+  if (dyn) {
+    if (wave == 0 && lane == 0) *mailbox = sched_resolve(g.sched, my_list, ticket, ntiles);
+    __syncthreads();
+    next_logical = __builtin_amdgcn_readfirstlane(*mailbox);
+    __syncthreads();        // every wave has read the word before the next tile's prologue DMA lands on it
+  }
 
   // opaque copies: nothing of the epilogue's address arithmetic may be hoisted above the K loop
   int lane_e = lane, m0e = m0, n0e = n0;
   asm volatile("" : "+v"(lane_e), "+s"(m0e), "+s"(n0e));
   epilogue_tile<EPI, 64>(g, acc, m0e, n0e, wr, wc, lane_e, 0);
+  logical = next_logical;
   }
+  if (dyn && tid == 0) sched_leave(g.sched, gridDim.x);
 }
 
 template <int LAYOUT, int EPI>
@@ -204,11 +232,17 @@ int launch2x_one(const GemmArgs& a, hipStream_t s) {
     configured = true;
   }
   int grid = a.ntm * a.ntn;
+  GemmArgs b = a;
+  b.sched = nullptr;
 #ifndef G2X_PERSIST
 #define G2X_PERSIST 1
 #endif
-  if (G2X_PERSIST && grid > 512) grid = 512;   // two resident workgroups per CU
-  gemm2x_kernel<LAYOUT, EPI><<<dim3(grid), T2, LDS2, s>>>(a);
+  const int nres = 2 * crl_gemm_cus();         // two resident workgroups per CU
+  if (G2X_PERSIST && grid > nres) {
+    grid = nres;
+    if (crl_gemm_dynamic()) { b.sched = crl_sched_slot(); if (!b.sched) return -2; }
+  }
+  gemm2x_kernel<LAYOUT, EPI><<<dim3(grid), T2, LDS2, s>>>(b);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(256x128)");
   return 0;
 }

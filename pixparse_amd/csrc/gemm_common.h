@@ -14,7 +14,43 @@ struct GemmArgs {
   int ntm, ntn;
   int kchunk;            // K tiles per split (gridDim.y splits; split s writes slab s of C)
   size_t slab_stride;    // elements between slabs
+  uint32_t* sched;       // dynamic tile scheduler state of this launch (persistent launches only, else nullptr): see TileSched
 };
+
+// ---- dynamic tile scheduler of the persistent kernels -------------------------------------------------------------------------
+// A persistent launch puts (at most) one workgroup on every CU it can get and lets the RESIDENT workgroups pull output tiles from
+// device-side ticket counters, instead of giving workgroup b the fixed list b, b + grid, b + 2 grid, ...: when some CUs are held by
+// another kernel (RCCL's all-reduce kernels while gradient buckets are in flight, include/crl.h crl_gemm_set_reserved_cus), the
+// workgroups that could not be placed simply find the queue empty when they finally start, and the launch takes
+// ceil(tiles / resident CUs) tile times instead of up to twice the undisturbed time.
+// State = 16 words: heads[0..7] = next position of XCD x's list, word 8 = workgroups that have left.  XCD x's list is the chunk of
+// the XCD-aware tile order that xcd_remap gives to blocks b = x (mod 8) (tiles that share operand panels stay in one L2); a
+// workgroup pulls from the list of the XCD it really runs on (HW_REG_XCC_ID) and steals from the next lists once its own is empty.
+// Every workgroup leaves through sched_leave(): the last one zeroes the state for the next launch that uses the slot (launches that
+// share a slot are ordered by their stream; the host rotates through CRL_SCHED_SLOTS slots).
+constexpr int CRL_SCHED_WORDS = 16, CRL_SCHED_SLOTS = 64;
+__device__ __forceinline__ int sched_xcd() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u); }   // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ int sched_list_len(int x, int ntiles) { return ntiles > x ? (ntiles - x + 7) >> 3 : 0; }
+__device__ __forceinline__ uint32_t sched_pull(uint32_t* head) {
+  return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// logical position (argument of xcd_remap) of the ticket `i` pulled from list x, or the next list with work left; -1 = all lists are
+// empty.  Called by ONE lane; x is advanced to the list that answered so that later pulls start there.
+__device__ __forceinline__ int sched_resolve(uint32_t* st, int& x, uint32_t i, int ntiles) {
+  for (int tries = 0;;) {
+    if ((int)i < sched_list_len(x, ntiles)) return x + 8 * (int)i;
+    if (++tries == 8) return -1;
+    x = (x + 1) & 7;
+    i = sched_pull(st + x);
+  }
+}
+__device__ __forceinline__ void sched_leave(uint32_t* st, uint32_t nwg) {   // one lane per workgroup, after its last pull
+  const uint32_t gone = __hip_atomic_fetch_add(st + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gone == nwg - 1) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) __hip_atomic_store(st + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // ---- swizzles (see the bank analysis in DESIGN.md "GEMM LDS images") ----
 template <int BK> __device__ __forceinline__ int km_swz(int row) {
@@ -74,5 +110,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int base, int ks, int
   return __builtin_bit_cast(bf16x8, both);
 }
 
-
 }  // namespace gemmc
+
+// host side of the scheduler / launch geometry (gemm.hip)
+uint32_t* crl_sched_slot();     // zeroed 16-word state for one persistent launch (rotating pool in device memory), nullptr on error
+int crl_gemm_cus();             // CUs the persistent kernels spread over: 256 minus crl_gemm_set_reserved_cus
+bool crl_gemm_dynamic();        // crl_gemm_set_schedule: dynamic tile tickets (default) or the static walk

@@ -10,7 +10,14 @@ rest of backward; ``finish()`` makes the compute stream wait for all of them.  T
 divided here: 1/world_size is folded into the unscale/clip coefficient of the optimiser kernel.
 xGMI is a full mesh of point-to-point links, so buckets are large (default 64 MiB) -- few, big
 collectives -- rather than DDP's 25 MiB.
+
+The collectives are issued through torch.distributed (backend "nccl" = RCCL), as the reference's DDP does: stream, channel count and
+event chaining are ProcessGroupNCCL's.  RCCL's kernels hold CUs while a bucket is in flight; the persistent GEMMs cope by pulling
+their tiles from ticket counters (include/crl.h crl_gemm_set_schedule), so a launch that finds CUs taken slows down by about the CU
+fraction.  PIXPARSE_AMD_RCCL_CUS=n additionally makes them launch on 256 - n CUs from the first bucket of a backward sweep until
+finish() (a whole number of tile rounds on the CUs that are left; worth it only when the collectives are long -- default 0, unset).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -36,6 +43,14 @@ class BucketedGradReducer:
         self.enabled = True
         self._next = 0
         self._works = []
+        self.reserved_cus = int(os.environ.get('PIXPARSE_AMD_RCCL_CUS', '0') or 0) if arena.p.is_cuda else 0
+        self._reserved_on = False
+
+    def _reserve(self, on: bool):
+        if self.reserved_cus and on != self._reserved_on:
+            from .. import ops
+            ops.gemm_set_reserved_cus(self.reserved_cus if on else 0)
+            self._reserved_on = on
 
     def broadcast_params(self, src: int = 0):
         """DDP constructor semantics (C1): every rank starts from rank 0's parameters."""
@@ -52,6 +67,7 @@ class BucketedGradReducer:
         g = self.arena.g
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
             s, e = self.buckets[self._next]
+            self._reserve(True)
             self._works.append(dist.all_reduce(g[s:e], op=self.op, group=self.group, async_op=True))
             self._next += 1
 
@@ -63,6 +79,7 @@ class BucketedGradReducer:
         for w in self._works:
             w.wait()
         self._works = []
+        self._reserve(False)
 
     def grad_divisor(self) -> float:
         return float(self.world_size) if (self.enabled and self.world_size > 1) else 1.0

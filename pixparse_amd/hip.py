@@ -24,6 +24,8 @@ SIGNATURES = {
     'crl_last_error': (c_char_p, []),
     'crl_gemm_ws_bytes': (Z, [I, I, L, L, L]),
     'crl_gemm_set_policy': (I, [I]),
+    'crl_gemm_set_schedule': (I, [I]),
+    'crl_gemm_set_reserved_cus': (I, [I]),
     'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, P, Z, P]),
     'crl_attn_decode_ws_bytes': (Z, [I, I, I]),
     'crl_attn_decode': (I, [P, L, P, L, L, P, L, L, P, L, I, I, I, F, P, P, L, P, Z, P]),
@@ -37,6 +39,7 @@ SIGNATURES = {
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
                          I, I, I, I, F, I, P]),
     'crl_attn_bwd_set_parts': (I, [I]),
+    'crl_debug_occupy_cus': (I, [I, ctypes.c_double, P, P]),
     'crl_prof_begin': (I, [I]),
     'crl_prof_end': (I, [I, P, P, P]),
     'crl_swin_attn_fwd': (I, [P, P, P, I, I, I, I, I, I, F, P]),

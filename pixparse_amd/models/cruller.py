@@ -60,6 +60,7 @@ class _TextDecoder(_Container):
         that re-run the decoder on the whole prefix like utils/ocr_utils.py:181-187."""
         owner = self._owner
         _, dec, _ = owner._ensure_engines()
+        dec.drop = None       # never the mask of an earlier training step (only forward_loss() sets one, backward() clears it)
         B, S, D = encoder_hidden_states.shape
         enc16 = encoder_hidden_states.reshape(B * S, D).to(torch.bfloat16).contiguous()
         T = input_ids.shape[1]
@@ -275,6 +276,7 @@ class Cruller(nn.Module):
     def decode_begin(self, encoder_outputs: torch.Tensor, max_len: int):
         """encoder_outputs [B, S, D] (fp32 or bf16): builds the cross-attention K/V and empty self-attention caches"""
         _, dec, _ = self._ensure_engines()
+        dec.drop = None
         B, S, D = encoder_outputs.shape
         enc16 = encoder_outputs.reshape(B * S, D).to(torch.bfloat16).contiguous()
         dec.decode_begin(enc16, B, S, int(max_len))
@@ -376,6 +378,7 @@ class Cruller(nn.Module):
         denc = bufs.get('denc', (dec.B * S, dec.D), torch.float32)     # written (not accumulated) by the decoder's last layer first
         dec.backward(bufs.t['dec.logits'], bufs.t[enc.tag + '.norm.y16'], denc, on_ready)
         enc.backward(denc, on_ready)
+        dec.drop = None       # the mask belongs to this forward_loss() / backward() pair only
 
     def activation_bytes(self) -> int:
         return 0 if self._engines is None else self._engines[2].bytes()

@@ -288,3 +288,36 @@ def dropout_mask(n: int, d: DropSpec, site: int, device) -> torch.Tensor:
 
 def add_bf16_to_f32(x_bf16, y, accumulate: bool) -> None:
     hip.call('crl_add_bf16_to_f32', _p(x_bf16), _p(y), x_bf16.numel(), int(accumulate), _stream())
+
+
+# ------------------------------------------------------------------------------------------- measurement aids
+def gemm_set_schedule(dynamic: bool) -> None:
+    """persistent GEMMs: dynamic tile tickets (default) or the static tile walk (A/B runs, tests); results are bit-identical"""
+    hip.call('crl_gemm_set_schedule', int(bool(dynamic)))
+
+
+def gemm_set_reserved_cus(n: int) -> None:
+    """persistent GEMMs launch on 256 - n CUs (the rest is left to RCCL's kernels while gradient buckets are in flight)"""
+    hip.call('crl_gemm_set_reserved_cus', int(n))
+
+
+class OccupyCUs:
+    """`with OccupyCUs(n):` -- n CUs are held by a sleeping side-stream kernel (crl_debug_occupy_cus) for the duration of the block:
+    the single-GPU stand-in for the CUs RCCL's all-reduce kernels take from the training step of a data-parallel run."""
+
+    def __init__(self, n_cus: int, max_seconds: float = 60.0):
+        self.n, self.max_seconds = int(n_cus), float(max_seconds)
+
+    def __enter__(self):
+        import time
+        self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        hip.call('crl_debug_occupy_cus', self.n, self.max_seconds, self.flag.data_ptr(), self.stream.cuda_stream)
+        time.sleep(0.02)          # the sleepers are resident before the disturbed work is enqueued
+        return self
+
+    def __exit__(self, *exc):
+        self.flag[0] = 1
+        self.stream.synchronize()
+        return False

@@ -3,7 +3,8 @@
       --master-port 29533 scripts/check_dp2_shared_gpu.py --out /tmp/dp2.pt
   python scripts/check_dp2_shared_gpu.py --reference /tmp/dp2.pt
 The first command runs TaskCrullerPretrain on two ranks (both on cuda:0, collectives over gloo) through the bucketed
-asynchronous gradient reducer; the second runs ONE process with grad_accum_steps=2 over the same four batches -- the
+asynchronous gradient reducer (without CRL_DEBUG_SHARED_GPU on a box with two devices the same command runs the real thing: one device per
+rank, backend nccl = RCCL -- tests/test_00_dist_gpu.py::test_rccl_two_ranks_equals_accum2); the second runs ONE process with grad_accum_steps=2 over the same four batches -- the
 same average of two per-batch mean-loss gradients -- and compares parameters, AdamW state and losses."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,6 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out')
     ap.add_argument('--reference')
+    ap.add_argument('--expect-backend', default=None, help="fail unless the process group runs on this backend ('nccl' = RCCL: two real devices)")
     a = ap.parse_args()
     ss = samples()
     if a.reference:
@@ -70,10 +72,13 @@ def main():
     import torch.distributed as dist
     t, env = make_task(accum=1)
     assert env.world_size == 2, 'launch with torchrun --nproc-per-node 2'
+    if a.expect_backend:
+        assert dist.get_backend() == a.expect_backend, f'process group runs on {dist.get_backend()!r}, expected {a.expect_backend!r}'
+        assert torch.cuda.current_device() == env.local_rank or env.device.index == env.local_rank, 'one device per rank'
     losses = []
     for k in range(2):
         t.train_step(ss[2 * k + env.global_rank])
-        l = torch.tensor([float(t.last_loss)], dtype=torch.float64)
+        l = torch.tensor([float(t.last_loss)], dtype=torch.float64, device=env.device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(l)
         losses.append(float(l) / 2)
     ar = t.model.arena

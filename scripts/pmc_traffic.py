@@ -12,7 +12,10 @@ then here:
 Units and the gfx950 correction (MI355X_MICROARCH.md "HBM"): both counters are in KiB; FETCH_SIZE reports exactly half of
 the bytes of wide (16 B per lane) coalesced reads -- every read of the kernels below is a 16-byte load or an LDS-DMA of 16
 bytes per lane -- so  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Infinity-Cache hits are counted, not excluded.
-Per kernel symbol the per-launch mean over all its dispatches in the run is written, next to the raw counter means."""
+Per kernel symbol the per-launch mean over all its dispatches in the run is written, next to the raw counter means, and
+the same split by launch geometry (`by_grid`: the ViT self-attention and the decoder's cross-attention launches of one symbol move
+different byte counts -- a mean over the mix is not comparable with either shape's algorithmic bytes).  `csrc_sha1` records the
+kernel sources the passes were taken from: bench.py drops `roofline.traffic` when the source of the dominant kernel has changed."""
 import csv
 import glob
 import json
@@ -39,6 +42,7 @@ def short(name):
 
 
 def read_pass(d, counter):
+    """{(kernel, grid size in threads): (mean counter value, launches)}; grid None = all launches of the symbol"""
     sums, cnt = defaultdict(float), defaultdict(int)
     files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
     assert files, f'no counter_collection.csv under {d}'
@@ -48,24 +52,36 @@ def read_pass(d, counter):
                 if row['Counter_Name'] != counter:
                     continue
                 k = short(row['Kernel_Name'])
-                sums[k] += float(row['Counter_Value'])
-                cnt[k] += 1
+                for key in ((k, None), (k, int(row.get('Grid_Size', 0) or 0))):
+                    sums[key] += float(row['Counter_Value'])
+                    cnt[key] += 1
     return {k: (sums[k] / cnt[k], cnt[k]) for k in sums}
+
+
+def csrc_sha1():
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'pixparse_amd', 'csrc')
+    return {os.path.basename(f): hashlib.sha1(open(f, 'rb').read()).hexdigest() for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h')))}
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fe, wr = read_pass(fetch_dir, 'FETCH_SIZE'), read_pass(write_dir, 'WRITE_SIZE')
     kernels = {}
-    for k in sorted(set(fe) & set(wr)):
-        f, nf = fe[k]
-        w, nw = wr[k]
-        kernels[k] = {'launches': min(nf, nw), 'FETCH_SIZE_KiB': round(f, 1), 'WRITE_SIZE_KiB': round(w, 1),
-                      'hbm_bytes_per_launch': int((2.0 * f + w) * 1024)}
+    for key in sorted(set(fe) & set(wr), key=lambda kg: (kg[0], kg[1] or 0)):
+        k, grid = key
+        f, nf = fe[key]
+        w, nw = wr[key]
+        rec = {'launches': min(nf, nw), 'FETCH_SIZE_KiB': round(f, 1), 'WRITE_SIZE_KiB': round(w, 1),
+               'hbm_bytes_per_launch': int((2.0 * f + w) * 1024)}
+        if grid is None:
+            kernels.setdefault(k, {}).update(rec)
+        else:
+            kernels.setdefault(k, {}).setdefault('by_grid', {})[str(grid)] = rec
     res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over `bench.py --steps 1 --warmup 1`, cfg-3; '
                      'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request); '
-                     'profiles/r2_pmc_traffic.json',
-           'kernels': kernels}
+                     + os.path.basename(out),
+           'csrc_sha1': csrc_sha1(), 'kernels': kernels}
     with open(out, 'w') as fh:
         json.dump(res, fh, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:25]:

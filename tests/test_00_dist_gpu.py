@@ -12,8 +12,12 @@ import subprocess
 import sys
 
 import pytest
+import torch          # device_count() below does not initialise the GPU: the child processes are the first to touch it
 
 pytestmark = pytest.mark.gpu
+N_GPUS = torch.cuda.device_count()
+needs_two_gpus = pytest.mark.skipif(N_GPUS < 2, reason=f'needs two MI355X for a real N > 1 RCCL run (this box has {N_GPUS}); '
+                                                         'RCCL refuses two ranks on one device')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -60,3 +64,35 @@ def test_dp2_on_shared_gpu_equals_grad_accum_2(tmp_path):
     assert r.returncode == 0 and os.path.exists(out), (r.stdout[-2000:], r.stderr[-4000:])
     r = subprocess.run([sys.executable, script, '--reference', out], capture_output=True, text=True, cwd=ROOT, timeout=900, env=_env())
     assert r.returncode == 0 and 'DP2 == ACCUM2: OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@needs_two_gpus
+def test_rccl_two_ranks_equals_accum2(tmp_path):
+    """cfg-4 in miniature, the day a multi-GPU box runs this suite: two ranks on two devices, backend `nccl` (= RCCL over xGMI), through
+    the bucketed asynchronous gradient reducer (fresh torchrun processes: nothing has touched the GPUs before the process group exists),
+    compared with ONE process running grad_accum_steps = 2 over the same four batches -- parameters, AdamW m / v, losses.
+    ref: task/task_cruller_pretrain.py:181-189,280-283; framework/device.py:116-135."""
+    out = str(tmp_path / 'dp2_rccl.pt')
+    script = os.path.join(ROOT, 'scripts', 'check_dp2_shared_gpu.py')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), script, '--out', out, '--expect-backend', 'nccl']
+    env = _env()
+    env.pop('CRL_DEBUG_SHARED_GPU', None)
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0 and os.path.exists(out), (r.stdout[-2000:], r.stderr[-4000:])
+    r = subprocess.run([sys.executable, script, '--reference', out], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0 and 'DP2 == ACCUM2: OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@needs_two_gpus
+def test_bench_two_ranks_rccl():
+    """the driver's N = 2 command line on a small config: both ranks finish, rank 0 prints one line, value counts both ranks' docs"""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--model', 'cruller_base_960x640', '--batch', '2', '--no-cpu-baseline', '--no-roofline']
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1200, env=_env())
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['collectives'] == 'rccl' and d['value'] > 0

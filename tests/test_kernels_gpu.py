@@ -192,6 +192,72 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy):
         hip.call('crl_gemm_set_policy', 0)
 
 
+def test_gemm_dynamic_tile_schedule(dev):
+    """persistent GEMMs (more tiles than resident workgroups) under the dynamic tile scheduler: bit-identical to the static walk for all
+    three layouts and both persistent kernels; the ticket counters are left zeroed by every launch (80 launches through a pool of 64
+    slots); with CUs reserved for RCCL (crl_gemm_set_reserved_cus) and with CUs taken away behind the library's back by a sleeping
+    side-stream kernel -- the workgroups that start late find the queue empty -- the results do not change"""
+    from pixparse_amd import hip, ops
+    M, N, K = 256 * 41 + 72, 2048, 192          # 42 x 8 = 336 tiles of 256 x 256 (672 of 256 x 128), ragged last row tile
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    w2 = rnd((K, N), dev, 0.1, 3, BF16)
+    bias = rnd((N,), dev, 0.5, 4)
+    res = rnd((M, N), dev, 1.0, 5)
+
+    def run():
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out)                                   # NT
+        y = torch.empty(M, N, dtype=F32, device=dev)
+        ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=res)       # NT + fp32 residual
+        o2 = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_dgrad(x, w2, o2)                                       # NN
+        return out, y, o2
+
+    try:
+        for policy in (2, 3, 0):
+            hip.call('crl_gemm_set_policy', policy)
+            ops.gemm_set_schedule(False)
+            want = run()
+            ops.gemm_set_schedule(True)
+            for rep in range(27):                                          # 81 persistent launches: the slot pool wraps
+                got = run()
+                if rep in (0, 26):
+                    for g, w_ in zip(got, want):
+                        assert torch.equal(g, w_), f'policy {policy} rep {rep}: dynamic schedule differs from the static walk'
+            for reserved in (32, 100):
+                ops.gemm_set_reserved_cus(reserved)
+                for g, w_ in zip(run(), want):
+                    assert torch.equal(g, w_), f'policy {policy}: result changed with {reserved} CUs reserved'
+                ops.gemm_set_reserved_cus(0)
+            with ops.OccupyCUs(48, max_seconds=20.0):
+                for sched in (True, False):
+                    ops.gemm_set_schedule(sched)
+                    for g, w_ in zip(run(), want):
+                        assert torch.equal(g, w_), f'policy {policy}: result changed with 48 CUs occupied (dynamic={sched})'
+                torch.cuda.synchronize()
+            ops.gemm_set_schedule(True)
+        ref = x.float() @ w.float().t() + bias.to(BF16).float()
+        close(want[0], ref, 1e-2, 1e-2, 'dynamic-schedule NT vs fp32')
+        # wgrad layout: split-K launches keep the static one-tile-per-workgroup form; a wgrad with more output tiles than CUs
+        # (17 x 20 tiles, short contraction) is a persistent launch and pulls tickets too
+        dy = rnd((512, 4352), dev, 1.0, 6, BF16)
+        xx = rnd((512, 5120), dev, 1.0, 7, BF16)
+        hip.call('crl_gemm_set_policy', 2)
+        dws = []
+        for sched in (False, True):
+            ops.gemm_set_schedule(sched)
+            dw = torch.zeros(4352, 5120, device=dev)
+            ops.linear_wgrad(dy, xx, dw, accumulate=False)
+            dws.append(dw)
+        assert torch.equal(dws[0], dws[1])
+        close(dws[1], dy.float().t() @ xx.float(), 2e-3, 0.2, 'TN persistent')
+    finally:
+        hip.call('crl_gemm_set_policy', 0)
+        ops.gemm_set_schedule(True)
+        ops.gemm_set_reserved_cus(0)
+
+
 def test_gemm_wave_quantisation_split(dev):
     """auto policy, 17 x 16 tiles of 256: the big kernel takes 16 row tiles (one full wave), the 128 kernel the last 104 rows"""
     from pixparse_amd import ops

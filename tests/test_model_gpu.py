@@ -181,6 +181,14 @@ def test_decoder_dropout_matches_oracle_with_the_same_masks(dev):
         tot = torch.sqrt(sum((op[k].grad.float() ** 2).sum() for k in params))
         assert abs(float(model.arena.g.norm()) - float(tot)) / float(tot) < 2e-2
     assert abs(losses[0] - plain) > 1e-4 * plain and abs(losses[0] - losses[1]) > 1e-5 * plain     # masks are live and change per micro-step
+    # the mask lives for ONE forward_loss() / backward() pair: the reference-style decoder call (ocr_utils) right after a training
+    # step -- dropout still switched on -- sees dropout-free logits, also when backward() was never called for that step
+    enc_states = model.image_encoder(image.to(dev))
+    clean = model(image.to(dev), ti.to(dev)).logits.float().clone()
+    after_bwd = model.text_decoder(ti.to(dev), enc_states).logits.float().clone()
+    model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev))        # sets a mask, no backward
+    no_bwd = model.text_decoder(ti.to(dev), enc_states).logits.float()
+    assert torch.equal(after_bwd, clean) and torch.equal(no_bwd, clean)
     model.set_train_dropout(False)
     assert float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev))) == plain
     out = model(image.to(dev), ti.to(dev))        # forward() alone (eval / generation paths) never drops

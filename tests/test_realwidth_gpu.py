@@ -155,6 +155,63 @@ def test_full_length_truncated_depth_vs_oracle(dev):
     print(f'\n[b] loss hip {loss:.6f} oracle {float(oloss):.6f}; worst grad rel-L2 {worst[0]}')
 
 
+# ------------------------------------------------------------------------------------------------ (b')
+def test_cfg3_full_depth_full_length_forward_loss_vs_oracle(dev):
+    """BASELINE.json north_star, literally: "loss within 1e-3 rel of reference" on cfg-3 itself -- cruller_large_1280x960, ALL 24
+    encoder blocks + 10 decoder layers at N = 6189 / T = 1023, V = 50267, batch 1.  Forward only: the oracle's bf16-policy forward is
+    ~8.5 TFLOP on the host cores (torch's fused CPU SDPA for the 6189^2 attention), a few minutes; the backward at this depth is
+    covered by (a) full depth / short sequences and (b) full length / 2 + 1 layers.  Also compared: the encoder output (what the ten
+    cross-attentions read) and the logits of sampled positions.  ref: task/task_cruller_pretrain.py:247-257."""
+    from oracle import ref_cpu as R
+    import os
+    torch.set_num_threads(os.cpu_count() or 1)
+    img, L, B = (1280, 960), 1024, 1
+    model, spec, params = _build_pair(dev, VIT_L, img, 'RGB', BART_L, 10, L, seed=14)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=8, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    e, d_, bufs = model._engines
+    assert e.N == 6189 and d_.T == 1023 and e.a['depth'] == 24 and d_.L == 10
+    enc_hip = bufs.t['vit.norm.y32'].float().cpu().clone()
+    out = model(image.to(dev), ti.to(dev))                      # forward() leaves clean logits in the buffer (forward_loss overwrote them)
+    rows = torch.tensor([0, 1, 17, 511, 1000, 1022])
+    logits_hip = out['logits'][0, rows.to(dev)].float().cpu()
+    with torch.no_grad():
+        oenc = R.vit_forward(params, spec.enc_arch, image, 'bf16', prefix='image_encoder.trunk.', fast_attn=True)
+        ologits = R.bart_decoder_forward(params, spec.dec_arch, 10, ti, oenc, 'bf16', prefix='text_decoder.trunk.', fast_attn=True)
+        oloss = float(R.cross_entropy(ologits, tt))
+    assert abs(loss - oloss) / oloss < 1e-3, (loss, oloss)
+    assert rel(enc_hip, oenc[0]) < 2e-2                         # 24 pre-LN blocks of bf16 GEMMs / attention on 6189 tokens
+    assert rel(logits_hip, ologits[0, rows]) < 3e-2
+    print(f'\n[b\'] cfg-3 full depth x full length: loss hip {loss:.6f} oracle {oloss:.6f} (rel {abs(loss - oloss) / oloss:.2e}); '
+          f'encoder output rel-L2 {rel(enc_hip, oenc[0]):.2e}')
+
+
+# ------------------------------------------------------------------------------------------------ (a')
+def test_cfg1_real_width_swin_tiny_bart_base_vs_oracle(dev):
+    """BASELINE.json configs[0] at its REAL widths: swin_tiny_patch4_window7_224 (C = 96 / 192 / 384 / 768, window 7, 3 / 6 / 12 / 24
+    heads of 32 channels, depths 2-2-6-2 with shifted windows and three patch mergings) + BART-base (D 768, 12 heads) x 2 layers, 224x224
+    images, 128-token targets, batch 2: loss and every parameter gradient against the oracle.  C = 96 is the only user of the
+    K % 64 != 0 branch of the 128x128 GEMM kernel (K = 96 -> 32-deep K tiles)."""
+    from oracle import ref_cpu as R
+    enc, dec = 'swin_tiny_patch4_window7_224', BART_B
+    img, L, B = (224, 224), 128, 2
+    model, spec, params = _build_pair(dev, enc, img, 'RGB', dec, 2, L, seed=15)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=9, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    oloss, ograds = _oracle_grads(spec, params, image, ti, tt, 'bf16')
+    with torch.no_grad():
+        ologits = R.cruller_forward(params, spec, image, ti, 'bf16')
+    out = model(image.to(dev), ti.to(dev))
+    assert out['logits'].shape == (B, L - 1, VOCAB)
+    assert rel(out['logits'], ologits) < 2e-2
+    loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    assert abs(loss - oloss) / oloss < 1e-3, (loss, oloss)
+    model.backward()
+    worst = _compare_grads(model, ograds, 5e-2, 2e-2)
+    print(f'\n[a\'] cfg-1 real width: loss hip {loss:.6f} oracle {oloss:.6f}; worst grad rel-L2 {worst[0]}')
+
+
 # ------------------------------------------------------------------------------------------------ (c)
 def _run_task(model_name, batch, steps, accum=1, seed0=100):
     from pixparse_amd.data import synthetic_batch
