@@ -303,7 +303,8 @@ def gemm_set_reserved_cus(n: int) -> None:
 
 class OccupyCUs:
     """`with OccupyCUs(n):` -- n CUs are held by a sleeping side-stream kernel (crl_debug_occupy_cus) for the duration of the block:
-    the single-GPU stand-in for the CUs RCCL's all-reduce kernels take from the training step of a data-parallel run."""
+    the single-GPU stand-in for the CUs RCCL's all-reduce kernels take from the training step of a data-parallel run.
+    Inside the block wait for work with `torch.cuda.current_stream().synchronize()`: a device-wide synchronize waits for the sleepers."""
 
     def __init__(self, n_cus: int, max_seconds: float = 60.0):
         self.n, self.max_seconds = int(n_cus), float(max_seconds)
