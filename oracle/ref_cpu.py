@@ -447,9 +447,15 @@ def greedy_generate(p: Dict[str, Tensor], spec: ModelSpec, encoder_outputs: Tens
                     max_recursion_length: int, policy: str = 'bf16', return_logits: bool = False):
     """utils/ocr_utils.py:165-197 get_generated_tokens with use_sample=False: the WHOLE decoder is re-run on the growing
     sequence for every new token (no KV cache); samples that already produced eos keep being extended until all have;
-    the token that completes the last sample is not appended."""
+    the token that completes the last sample is not appended.  prompt_id: one token id, or a multi-token prompt (list of ids /
+    [B, P] tensor) as the DocVQA / CORD eval loops start from (task/task_cruller_eval_docvqa.py:279-297: the decoder is re-run on
+    `<s_docvqa><s_question>...</s_question><s_answer>` + everything generated so far)."""
     B = encoder_outputs.shape[0]
-    input_ids = torch.full((B, 1), prompt_id, dtype=torch.int64)
+    if isinstance(prompt_id, int):
+        input_ids = torch.full((B, 1), prompt_id, dtype=torch.int64)
+    else:
+        input_ids = torch.as_tensor(prompt_id, dtype=torch.int64)
+        input_ids = input_ids.view(1, -1).expand(B, -1).clone() if input_ids.dim() == 1 else input_ids.clone()
     finished = torch.zeros(B, dtype=torch.bool)
     steps = []
     for _ in range(max_recursion_length):

@@ -521,7 +521,8 @@ class BartEngine(_Base):
         if x.shape[0] <= ops.SKINNY_MAX_ROWS:
             ops.linear_skinny(x, w, b, out, epi, resid=resid)
         else:
-            ops.linear_fwd(x, w, b, out, epi, resid=resid)
+            aux = self.buf('gen.gelu_pre', out.shape, BF16) if epi == EPI_BF16_GELU else None   # the GEMM epilogue also stores the pre-activation
+            ops.linear_fwd(x, w, b, out, epi, aux=aux, resid=resid)
 
     def decode_begin(self, enc16: torch.Tensor, B: int, S: int, max_len: int):
         """enc16 bf16 [B*S, D].  Projects the encoder states to every layer's cross-attention K/V once and lays out
@@ -538,6 +539,53 @@ class BartEngine(_Base):
             kv2 = self.buf(f'gen.l{i}.kv2', (B * S, 2 * D), BF16)
             ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
             self.buf(f'gen.l{i}.kvc', (B, max_len, 3 * D), BF16)      # q | k | v of every step: one fused projection per token
+
+    def decode_prefill(self, ids: torch.Tensor) -> None:
+        """ids [B, P]: the first P tokens of a multi-token prompt (every sequence the same length), positions 0..P-1 of an empty
+        cache.  ONE pass of the whole decoder over the P rows -- the training forward's layer arithmetic (fused q|k|v projection,
+        causal flash attention, cross-attention over the K/V that decode_begin projected) -- whose q|k|v rows land in cache rows
+        0..P-1; no logits are produced (the caller feeds the prompt's LAST token through decode_step, which yields the first
+        generated token).  ref: the reference re-runs the decoder on the whole prompt for every generated token
+        (task/task_cruller_eval_docvqa.py:279-297, task_cruller_eval_cord.py:345-372)."""
+        g = self.gen
+        B, S, step = g['B'], g['S'], g['step']
+        P_ = ids.shape[1]
+        assert ids.shape[0] == B and g['t'] == 0 and 0 < P_ < g['max_len'], 'prefill starts from an empty cache and must leave room to decode'
+        dp, D, F_, H = self.DP, self.D, self.F, self.heads
+        M = B * P_
+        eps = self.a['ln_eps']
+        scale = (D // H) ** -0.5
+        emb = self.buf('pre.emb', (M, D), F32)
+        ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2)
+        h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'pre.ln_emb', eps, want_f32=True, want_bf16=True)
+        for i in range(self.L):
+            lp, k = dp + f'layers.{i}.', f'pre.l{i}'
+            kvc = self.bufs.t[self.tag + f'.gen.l{i}.kvc']
+            qkv = self.buf('pre.qkv', (M, 3 * D), BF16)
+            self._lin(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), qkv)
+            rows = kvc[:, :P_, :]
+            rows.copy_(qkv.view(B, P_, 3 * D))                          # cache rows 0..P-1 (memory movement only)
+            o1 = self.buf('pre.o1', (M, D), BF16)
+            lse = self.buf('pre.lse', (B, H, P_), F32)
+            ops.attn_fwd(rows[:, :, 0:D], rows[:, :, D:2 * D], rows[:, :, 2 * D:], o1.view(B, P_, D), lse, H, scale, True)
+            t1 = self.buf('pre.t1', (M, D), F32)
+            self._lin(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
+            h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, 'pre.ln1', eps, True, True)
+            q2 = self.buf('pre.q2', (M, D), BF16)
+            self._lin(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
+            kv3 = self.bufs.t[self.tag + f'.gen.l{i}.kv2'].view(B, S, 2 * D)
+            o2 = self.buf('pre.o2', (M, D), BF16)
+            ops.attn_fwd(q2.view(B, P_, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, P_, D), lse, H, scale, False)
+            t2 = self.buf('pre.t2', (M, D), F32)
+            self._lin(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
+            h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, 'pre.ln2', eps, True, True)
+            act = self.buf('pre.act', (M, F_), BF16)
+            self._lin(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU)
+            t3 = self.buf('pre.t3', (M, D), F32)
+            self._lin(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, EPI_F32_RESID, resid=h2)
+            h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, f'pre.ln3.{i & 1}', eps, True, True)   # h / hb of layer i feed layer i + 1: two alternating buffers
+        step.fill_(P_)
+        g['t'] = P_
 
     def decode_step(self, ids: torch.Tensor) -> torch.Tensor:
         """ids [B, 1] = the token at position step (= number of tokens fed so far) -> logits bf16 [B, Vp] for the next

@@ -281,16 +281,24 @@ class Cruller(nn.Module):
         enc16 = encoder_outputs.reshape(B * S, D).to(torch.bfloat16).contiguous()
         dec.decode_begin(enc16, B, S, int(max_len))
 
+    def decode_prefill(self, prompt_ids: torch.Tensor) -> None:
+        """prompt_ids [B, P]: the first P tokens of every sequence in ONE decoder pass that fills cache rows 0..P-1 (no logits);
+        feed the prompt's last token through decode_step() next"""
+        _, dec, _ = self._ensure_engines()
+        dec.decode_prefill(prompt_ids.contiguous())
+
     def decode_step(self, input_ids: torch.Tensor) -> torch.Tensor:
         """input_ids [B, 1]: the next token of every sequence -> next-token logits bf16 [B, V]"""
         _, dec, _ = self._ensure_engines()
         return dec.decode_step(input_ids.contiguous())[:, :self.vocab_size]
 
-    def generate_greedy(self, encoder_outputs: torch.Tensor, prompt_id: int, eos_id: int, max_steps: int,
+    def generate_greedy(self, encoder_outputs: torch.Tensor, prompt_id, eos_id: int, max_steps: int,
                         use_graph: bool = True, return_logits: bool = False, check_every: int = 8):
         """The reference's greedy loop (utils/ocr_utils.py:165-197) on the KV-cache decode path: every sequence starts
         from prompt_id; iteration r appends arg-max token r unless ALL sequences have produced eos by then (the token of
-        that iteration is not appended). The step has no host-visible state (position, cache row and key count come from
+        that iteration is not appended). prompt_id may also be a multi-token prompt (a list of ids, the same for every sequence, or an
+        int64 tensor [B, P]): all but its last token go through one prefill pass (decode_prefill), the last one starts the loop;
+        the returned ids then begin with the whole prompt. The step has no host-visible state (position, cache row and key count come from
         a device counter), so after one eager iteration it is captured in a hipGraph and replayed; the host only reads
         the "all finished at iteration" flag every `check_every` replays. Returns ids [B, n] (and the per-iteration
         fp32 logits when return_logits, which forces the eager path)."""
@@ -298,11 +306,19 @@ class Cruller(nn.Module):
         dev = self.device
         B = encoder_outputs.shape[0]
         V = self.vocab_size
-        self.decode_begin(encoder_outputs, max_steps + 1)
+        if isinstance(prompt_id, int):
+            prompt = torch.full((B, 1), prompt_id, dtype=torch.int64, device=dev)
+        else:
+            prompt = torch.as_tensor(prompt_id, dtype=torch.int64, device=dev)
+            prompt = prompt.view(1, -1).expand(B, -1).contiguous() if prompt.dim() == 1 else prompt
+        P_ = prompt.shape[1]
+        self.decode_begin(encoder_outputs, max_steps + P_)
+        if P_ > 1:
+            self.decode_prefill(prompt[:, :-1])
         ids = bufs.get('gen.ids', (B, 1), torch.int64)
-        ids.fill_(prompt_id)
+        ids.copy_(prompt[:, -1:])
         tokens = bufs.get('gen.tokens', (B, max_steps + 1), torch.int64)
-        tokens.fill_(prompt_id)
+        tokens.copy_(prompt[:, -1:].expand(B, max_steps + 1))
         finished = bufs.get('gen.finished', (B,), torch.bool)
         finished.zero_()
         done_at = bufs.get('gen.done_at', (1,), torch.int32)
@@ -346,7 +362,7 @@ class Cruller(nn.Module):
                 n_done += 1
         d = int(done_at.item())
         n_tokens = 1 + (d if d >= 0 else n_done)
-        out = tokens[:, :n_tokens].clone()
+        out = torch.cat([prompt[:, :-1], tokens[:, :n_tokens]], dim=1)
         return (out, steps[:n_tokens if d < 0 else d + 1]) if return_logits else out
 
     def forward_loss(self, image_input, text_input, text_target, loss_mul: float = 1.0, grad_mul: float = 1.0,

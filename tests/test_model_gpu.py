@@ -411,6 +411,64 @@ def test_greedy_generation_with_kv_cache_vs_oracle(dev, enc, img, fmt, B):
     assert len(texts) == B and all(t.startswith('<s_pretrain>') for t in texts)
 
 
+def test_greedy_generation_with_prompt_prefill_vs_oracle(dev):
+    """f-4 (DocVQA / CORD eval loops, ref task/task_cruller_eval_docvqa.py:279-297): generation from a 12-token prompt.  All but the
+    prompt's last token go through ONE prefill pass of the decoder that fills the KV cache, then the single-token decode steps take over
+    (eager and hipGraph replay).  Against the oracle's restatement of the reference loop, which re-runs the whole decoder on prompt +
+    generated tokens for every step: per-step logits, every chosen token an arg-max of the oracle's logits within the bf16 tolerance,
+    and the cache rows written by the prefill equal to the rows the token-by-token path writes (same kernels per row up to the GEMM
+    shape: bf16 tolerance)."""
+    from oracle import ref_cpu as R
+    from pixparse_amd.models import Cruller
+    _register_test_archs()
+    enc, img, fmt, B = 'vit_test', (37, 50), 'RGB', 2
+    layers, L, V = 2, 48, 515
+    torch.manual_seed(12)
+    model = Cruller(_cfg(enc, img, fmt, layers, L), vocab_size=V)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.bias'):
+                p.normal_(0, 0.05)
+            elif p.dim() >= 2:
+                p.mul_(4.0)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith('lm_head.weight')}
+    spec = R.ModelSpec(enc, 'bart_test', layers, L, img, 3, vocab=V)
+    image, _, _ = R.synthetic_sample(spec, B, seed=10)
+    model.to(dev)
+    model._ensure_engines()
+    model.refresh_shadows(full=True)
+    enc_out = model.image_encoder(image.to(dev))
+    prompt = [514, 7, 301, 44, 9, 120, 77, 300, 5, 63, 410, 513]          # <s_task> ... <s_answer>: 12 tokens, the same for both samples
+    steps_max = 10
+    ids, logits = model.generate_greedy(enc_out, prompt, 2, steps_max, use_graph=False, return_logits=True)
+    assert ids[:, :12].tolist() == [prompt] * B and 12 <= ids.shape[1] <= 12 + steps_max
+    oenc = R.encode_image(params, spec, image, 'bf16')
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    for t in range(len(logits)):
+        ol = R.bart_decoder_forward(params, spec.dec_arch, layers, ids[:, :12 + t].cpu(), oenc, 'bf16', prefix='text_decoder.trunk.')[:, -1, :].float()
+        assert close(logits[t].cpu(), ol, 3e-2), (t, float((logits[t].cpu() - ol).abs().max()))
+        if 12 + t < ids.shape[1]:
+            chosen = ids[:, 12 + t].cpu()
+            margin = ol.max(-1).values - ol.gather(1, chosen[:, None])[:, 0]
+            assert float(margin.max()) <= 3e-2 * max(1.0, float(ol.abs().max())), (t, margin)
+    oids = R.greedy_generate(params, spec, oenc, prompt, 2, steps_max, 'bf16')
+    assert oids[:, :12].tolist() == [prompt] * B
+    g_ids = model.generate_greedy(enc_out, prompt, 2, steps_max, use_graph=True)
+    t_ids = model.generate_greedy(enc_out, torch.tensor([prompt, prompt]), 2, steps_max, use_graph=False)      # [B, P] tensor form
+    assert torch.equal(g_ids, ids) and torch.equal(t_ids, ids)
+    # the cache after prefill(11 tokens) == the cache after feeding the same 11 tokens one by one
+    _, dec, bufs = model._engines
+    model.decode_begin(enc_out, 16)
+    model.decode_prefill(torch.tensor([prompt[:-1]] * B, device=dev))
+    pre = [bufs.t[f'dec.gen.l{i}.kvc'][:, :11].float().clone() for i in range(layers)]
+    model.decode_begin(enc_out, 16)
+    for t in range(11):
+        model.decode_step(torch.full((B, 1), prompt[t], dtype=torch.int64, device=dev))
+    for i in range(layers):
+        one = bufs.t[f'dec.gen.l{i}.kvc'][:, :11].float()
+        assert float((pre[i] - one).abs().max()) <= 3e-2 * max(1.0, float(one.abs().max())), i
+
+
 def test_eval_ocr_task_step(dev):
     """f-4: cruller_eval_ocr through TaskFactory: checkpoint hand-over, step() = encode + KV-cache generation + CER / WER"""
     from oracle import ref_cpu as R
