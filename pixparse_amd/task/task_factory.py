@@ -1,15 +1,15 @@
 """name -> (TaskCls, CfgCls) registry (ref: task/task_factory.py:44-79).  The pretrain task is the hot path; the
-fine-tune tasks reuse its step; the reference's eval / xent entries are not built and raise a
-clear error."""
+fine-tune tasks reuse its step, the eval tasks (f-4) the KV-cache generation path; `donut_eval_ocr` (a
+different model family) and `cruller_finetune_xent` are not built and raise a clear error."""
 from ..framework import DeviceEnv, Monitor
 from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
 from .task_cruller_eval_ocr import TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg
 from .task_cruller_eval_rvlcdip import TaskCrullerEvalRVLCDIP, TaskCrullerEvalRVLCDIPCfg
+from .task_cruller_eval_docvqa import TaskCrullerEvalCORD, TaskCrullerEvalCORDCfg, TaskCrullerEvalDOCVQA, TaskCrullerEvalDOCVQACfg
 from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
                                     TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 
-_NOT_BUILT = ('cruller_eval_cord', 'cruller_eval_docvqa', 'donut_eval_ocr',
-              'cruller_finetune_xent')
+_NOT_BUILT = ('donut_eval_ocr', 'cruller_finetune_xent')
 
 
 class TaskFactory:
@@ -17,6 +17,8 @@ class TaskFactory:
         'cruller_pretrain': (TaskCrullerPretrain, TaskCrullerPretrainCfg),
         'cruller_eval_ocr': (TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg),
         'cruller_eval_rvlcdip': (TaskCrullerEvalRVLCDIP, TaskCrullerEvalRVLCDIPCfg),
+        'cruller_eval_cord': (TaskCrullerEvalCORD, TaskCrullerEvalCORDCfg),
+        'cruller_eval_docvqa': (TaskCrullerEvalDOCVQA, TaskCrullerEvalDOCVQACfg),
         'cruller_finetune_rvlcdip': (TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg),
         'cruller_finetune_cord': (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg),
         'cruller_finetune_docvqa': (TaskCrullerFinetuneDOCVQA, TaskCrullerFinetuneDOCVQACfg),

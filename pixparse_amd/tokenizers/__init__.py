@@ -4,8 +4,9 @@
 network and no cached `facebook/bart-large` files, so a byte-level stand-in with BART's special ids (bos 0, pad 1, eos 2,
 vocab 50265) exists for synthetic benches and tests.  It is never substituted silently:
   * `TokenizerCfg(name='byte-bart')` selects it explicitly (bench.py and the tests do);
-  * any other name is loaded through transformers (local cache first, then the hub unless HF_HUB_OFFLINE is set);
-    if that fails the error is logged at WARNING level with the reason and the stand-in is used -- its vocabulary is
+  * any other name is loaded through transformers from LOCAL files only (cache / directory); the hub is contacted only when
+    PIXPARSE_AMD_ALLOW_HUB=1 says so -- the training boxes have no network, and every rank stalling in hub retries at start-up
+    helps nobody; if that fails the error is logged at WARNING level with the reason and the stand-in is used -- its vocabulary is
     INCOMPATIBLE with real BART checkpoints -- unless PIXPARSE_AMD_STRICT_TOKENIZER=1, which re-raises."""
 import logging
 import os
@@ -40,6 +41,10 @@ class ByteBartTokenizer:
 
     def __len__(self):
         return self.base_vocab + len(self.added)
+
+    @property
+    def all_special_tokens(self):
+        return [self.bos_token, self.eos_token, self.unk_token, self.pad_token, *self.added]
 
     def convert_tokens_to_ids(self, tok):
         fixed = {self.bos_token: 0, self.pad_token: 1, self.eos_token: 2, self.unk_token: 3}
@@ -110,7 +115,7 @@ class TokenizerHF:
             try:
                 self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name, local_files_only=True)
             except Exception:
-                if os.environ.get('HF_HUB_OFFLINE', '0') == '1':
+                if os.environ.get('PIXPARSE_AMD_ALLOW_HUB', '0') != '1' or os.environ.get('HF_HUB_OFFLINE', '0') == '1':
                     raise
                 self.trunk = transformers.AutoTokenizer.from_pretrained(cfg.name)
         except Exception as e:  # noqa: BLE001  (import error, cache miss, no network, typo in the name ...)

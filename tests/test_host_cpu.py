@@ -556,6 +556,192 @@ def test_eval_rvlcdip_counting_rule_with_scripted_decoder():
     assert b['image'].shape == (2, 1, 32, 40) and b['label'].tolist() == [3, 4]
 
 
+def test_eval_metrics_known_answers_and_tree_edit_distance():
+    """utils/metrics.py restates Levenshtein / nltk edit_distance / zss (none installable): ANLS and nTED / F1 known answers computed
+    by hand, the zss README example, and Zhang-Shasha against an independent exhaustive recursion on random ordered trees with the
+    evaluator's own (leaf-aware, non-uniform) costs"""
+    import random
+    from functools import lru_cache
+    from pixparse_amd.utils.metrics import (JSONParseEvaluator, Node, average_normalized_levenshtein_similarity, edit_distance,
+                                            normalized_levenshtein, similarity_score, tree_edit_distance)
+    assert edit_distance('kitten', 'sitting') == 3 and edit_distance('', 'abc') == 3 and edit_distance('abc', 'abc') == 0
+    assert normalized_levenshtein('hello', 'help') == 2 / 5 and similarity_score('hello', 'help') == 1 - 2 / 5
+    assert similarity_score('abcd', 'wxyz') == 0                               # nl = 1 >= tau
+    assert average_normalized_levenshtein_similarity([['abc', 'abd'], ['hello']], ['abc', 'help']) == (1.0 + 0.6) / 2
+    unit = dict(insert_cost=lambda n: 1, remove_cost=lambda n: 1, update_cost=lambda a, b: int(a.label != b.label))
+    A = Node('f').addkid(Node('a').addkid(Node('h')).addkid(Node('c').addkid(Node('l')))).addkid(Node('e'))
+    B = Node('f').addkid(Node('a').addkid(Node('d')).addkid(Node('c').addkid(Node('b')))).addkid(Node('e'))
+    assert tree_edit_distance(A, B, **unit) == 2                               # the example of the zss README
+    ev = JSONParseEvaluator()
+    gt = {'menu': [{'nm': 'cake', 'cnt': '2'}, {'nm': 'juice', 'cnt': '1'}], 'total': {'price': '9'}}
+    pr = {'menu': [{'nm': 'cake', 'cnt': '2'}, {'nm': 'juic', 'cnt': '1'}]}
+    assert ev.cal_acc(gt, gt) == 1.0 and ev.cal_f1([gt], [gt]) == 1.0
+    # gt tree costs 22 to insert (15 inner nodes + leaves 'cake' '2' 'juice' '1' '9'); pr lacks total->subtree->price->'9' (4) and one letter
+    assert abs(ev.cal_acc(pr, gt) - (1 - 5 / 22)) < 1e-12 and abs(ev.cal_f1([pr], [gt]) - 3 / 4.5) < 1e-12
+    assert ev.cal_acc({}, gt) == 0 and ev.flatten(ev.normalize_dict(gt))[0] == ('menu.nm', 'cake')
+    c = dict(insert_cost=ev.insert_and_remove_cost, remove_cost=ev.insert_and_remove_cost, update_cost=ev.update_cost)
+
+    def freeze(n):
+        return (n.label, tuple(freeze(k) for k in n.children))
+
+    @lru_cache(maxsize=None)
+    def forest(F, G):      # exhaustive forest edit distance on the rightmost roots (Zhang-Shasha's recurrence without its bookkeeping)
+        if not F and not G:
+            return 0
+        if not G:
+            (l, kids) = F[-1]
+            return forest(F[:-1] + kids, G) + c['remove_cost'](Node(l))
+        if not F:
+            (l, kids) = G[-1]
+            return forest(F, G[:-1] + kids) + c['insert_cost'](Node(l))
+        (lf, kf), (lg, kg) = F[-1], G[-1]
+        return min(forest(F[:-1] + kf, G) + c['remove_cost'](Node(lf)), forest(F, G[:-1] + kg) + c['insert_cost'](Node(lg)),
+                   forest(F[:-1], G[:-1]) + forest(kf, kg) + c['update_cost'](Node(lf), Node(lg)))
+
+    rng = random.Random(3)
+
+    def rand_tree(depth):
+        if depth == 0 or rng.random() < 0.3:
+            return Node('<leaf>' + rng.choice(['a', 'ab', 'xyz', 'abcd', '']))
+        n = Node(rng.choice(['menu', 'nm', '<subtree>', 'total']))
+        for _ in range(rng.randint(1, 3)):
+            n.addkid(rand_tree(depth - 1))
+        return n
+    for _ in range(40):
+        a, b = rand_tree(3), rand_tree(3)
+        assert tree_edit_distance(a, b, **c) == forest((freeze(a),), (freeze(b),))
+
+
+def test_eval_docvqa_and_cord_with_scripted_decoder():
+    """cruller_eval_docvqa / cruller_eval_cord (ref task_cruller_eval_docvqa.py:270-313, task_cruller_eval_cord.py:335-385): prompt strings,
+    string-carried generation with the '</s>' stop rule, token2json of the result, ANLS and nTED / F1 -- the decoder scripted so that
+    the expected numbers can be written down; plus generate_string's rule that the decoder is always fed the ids the re-tokenised
+    STRING has (the reference's loop), re-prefilling when they are not `previous ids + new id`"""
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    from pixparse_amd.models.archs import register_arch
+    from pixparse_amd.task import TaskCrullerEvalCORD, TaskCrullerEvalDOCVQA, TaskFactory
+    from pixparse_amd.task.task_cruller_eval_docvqa import generate_string
+    import numpy as np
+    register_arch('vit', 'vit_ft_test', dict(patch=8, dim=128, depth=1, heads=2, mlp_ratio=4, ln_eps=1e-6, pre_norm=False, mean=(0.5,) * 3, std=(0.25,) * 3))
+    register_arch('bart', 'bart_ft_test', dict(d_model=128, heads=2, ffn=256, ln_eps=1e-5, vocab=509, dropout=0.0))
+    model = ModelCfg(image_encoder=ImageEncoderCfg(name='vit_ft_test', image_fmt='L', image_size=(32, 40), pretrained=False),
+                     text_decoder=TextDecoderCfg(name='bart_ft_test', pretrained=False, num_decoder_layers=1, max_length=128))
+    env = DeviceEnv(init_device_type='cpu')
+
+    class Fake:
+        """decode path that emits, per sample, the tokens of a scripted answer string; records what it was fed"""
+        max_length = 128
+
+        def __init__(self, tok, answers):
+            self.tok, self.answers, self.k, self.fed, self.prefills = tok, answers, -1, [], []
+        def image_encoder(self, x):
+            return torch.zeros(x.shape[0], 3, 128)
+        def decode_begin(self, enc, max_len):
+            self.cache = []
+        def decode_prefill(self, ids):
+            self.cache = ids[0].tolist()
+            self.prefills.append(list(self.cache))
+        def start_sample(self):
+            self.k += 1
+            self.out = self.tok.encode(self.answers[self.k], add_special_tokens=False)
+            self.pos = 0
+        def decode_step(self, ids_in):
+            self.cache.append(int(ids_in[0, 0]))
+            self.fed.append(list(self.cache))
+            logits = torch.full((1, len(self.tok)), -1.0)
+            logits[0, self.out[self.pos]] = 1.0
+            self.pos += 1
+            return logits
+
+    # ---- DocVQA
+    task, _ = TaskFactory.create_task('cruller_eval_docvqa', dict(model=model, dtype='bfloat16'), env, None)
+    assert isinstance(task, TaskCrullerEvalDOCVQA) and task.vocab_size == 50267 + 5 == task.model.vocab_size
+    tok = task.tokenizer.trunk
+    answers = ['42 USD</s_answer></s>', 'no closing tag</s>']
+    fake = Fake(tok, answers)
+    task.model = fake
+    task.all_ground_truths, task.all_predictions, task.acc_list = [], [], []
+    items = [{'image': np.zeros((50, 60), np.uint8), 'labels': {'question': 'total?', 'answers': ['42 USD', '42']}, 'image_id': 1, 'question_id': 10},
+             {'image': np.zeros((50, 60, 3), np.uint8), 'labels': {'question': 'who', 'answers': ['x']}, 'image_id': 2, 'question_id': 11}]
+    batch = task.collate_fn(items)
+    assert batch['images'].shape == (2, 1, 32, 40) and batch['questions'] == ['total?', 'who'] and batch['question_ids'] == [10, 11]
+    real_begin = fake.decode_begin
+    def counted_begin(enc, max_len):
+        real_begin(enc, max_len)
+        fake.start_sample()
+    fake.decode_begin = counted_begin
+    task.step(batch)
+    assert task.all_predictions == ['42 USD', ''] and task.all_ground_truths == [['42 USD', '42'], ['x']]
+    assert task.average_metrics({}) == {'ANLS': 0.5}
+    prompt0 = tok.encode('<s_docvqa><s_question>total?</s_question><s_answer>', add_special_tokens=False)
+    assert fake.prefills[0] == prompt0[:-1] and fake.fed[0] == prompt0                      # prefill all but the last prompt token, then feed it
+    assert fake.fed[1] == prompt0 + tok.encode('4', add_special_tokens=False)                # every step sees prompt + everything generated
+    assert len(fake.prefills) == 2                                                           # one prefill per sample: no re-tokenisation mismatch
+
+    # ---- CORD
+    task, _ = TaskFactory.create_task('cruller_eval_cord', dict(model=model, dtype='bfloat16'), env, None)
+    assert isinstance(task, TaskCrullerEvalCORD) and task.vocab_size == 50267 + 1 + 54 == task.model.vocab_size
+    tok = task.tokenizer.trunk
+    gts = [{'gt_parse': {'menu': [{'nm': 'cake', 'cnt': '2'}, {'nm': 'juice', 'cnt': '1'}], 'total': {'total_price': '9'}}},
+           {'gt_parse': {'menu': {'nm': 'tea'}}}]
+    batch = task.collate_fn([{'image': np.zeros((50, 60), np.uint8), 'ground_truth': repr(g)} for g in gts])
+    assert batch['label'].shape == (2, 511) and batch['text_target'].shape == (2, 511) and batch['label'][0, 0] == tok.convert_tokens_to_ids('<s_cord>')
+    assert (batch['text_target'][0] == -100).sum() > 400 and batch['text_target'][0, 0] == tok.convert_tokens_to_ids('<s_menu>')
+    fake = Fake(tok, ['<s_menu><s_nm>cake</s_nm><s_cnt>2</s_cnt><sep/><s_nm>juic</s_nm><s_cnt>1</s_cnt></s_menu></s>',
+                      '<s_menu><s_nm>tea</s_nm></s_menu></s>'])
+    real_begin2 = fake.decode_begin
+    def counted_begin2(enc, max_len):
+        real_begin2(enc, max_len)
+        fake.start_sample()
+    fake.decode_begin = counted_begin2
+    task.model = fake
+    task.all_ground_truths, task.all_predictions, task.acc_list = [], [], []
+    from pixparse_amd.utils.metrics import JSONParseEvaluator
+    task.evaluator = JSONParseEvaluator()
+    m = task.step(batch)
+    assert m['batch_accuracy'] == 1.0                                                         # the last sample of the batch (ref :383)
+    avg = task.average_metrics({0: m})
+    assert abs(avg['average_accuracy'] - ((1 - 5 / 22) + 1.0) / 2) < 1e-12 and abs(avg['f1_score'] - 4 / 5.5) < 1e-12
+    assert task.all_predictions == [] and fake.prefills == []                                 # one-token prompt: no prefill; state cleared like the reference
+
+    # ---- generate_string follows the STRING: a tokenizer that merges 'a' + 'b' into one id forces a cache rebuild
+    class MergeTok:
+        eos_token, pad_token_id = '</s>', 1
+        vocab = {'<p>': 10, 'a': 11, 'b': 12, 'ab': 13, '</s>': 2}
+        def __len__(self):
+            return 20
+        def encode(self, text, add_special_tokens=False):
+            out, i = [], 0
+            keys = sorted(self.vocab, key=len, reverse=True)
+            while i < len(text):
+                for k in keys:
+                    if text.startswith(k, i):
+                        out.append(self.vocab[k]); i += len(k); break
+            return out
+        def decode(self, ids):
+            inv = {v: k for k, v in self.vocab.items()}
+            return ''.join(inv[i] for i in ids)
+    class Tk:
+        trunk = MergeTok()
+    class Fake2(Fake):
+        def __init__(self):
+            self.fed, self.prefills, self.script, self.pos = [], [], [11, 12, 2], 0
+        def decode_step(self, ids_in):
+            self.cache.append(int(ids_in[0, 0]))
+            self.fed.append(list(self.cache))
+            logits = torch.full((1, 20), -1.0)
+            logits[0, self.script[self.pos]] = 1.0
+            self.pos += 1
+            return logits
+    f2 = Fake2()
+    stats = {}
+    text = generate_string(f2, Tk, torch.zeros(3, 8), '<p>', torch.device('cpu'), stats=stats)
+    assert text == '<p>ab</s>'
+    # after 'a' then 'b' the string '<p>ab' tokenises to [10, 13], not [10, 11, 12]: the decoder is re-prefilled with [10] and fed 13
+    assert f2.fed == [[10], [10, 11], [10, 13]] and f2.prefills == [[10]] and stats['prefills'] == 2
+
+
 # ------------------------------------------------------------------------------------------- pretrained weights / tokenizer
 def _tiny_archs():
     from pixparse_amd.models.archs import register_arch

@@ -528,6 +528,57 @@ def test_eval_rvlcdip_task_step_gpu(dev):
     assert c['n_valid_samples'] == 4 and 0 <= c['correct_samples'] <= 4
 
 
+def test_eval_docvqa_and_cord_task_steps_gpu(dev):
+    """cruller_eval_docvqa / cruller_eval_cord end to end on the device (random weights): multi-token prompt prefill + KV-cache steps
+    inside the reference's string-carried loop.  The generated text is checked against the reference's own way of running it -- the
+    UNCACHED decoder re-run on the re-tokenised string for every token (model.text_decoder(**prepare_inputs_for_inference(...)),
+    task_cruller_eval_docvqa.py:279-297): every token the cached loop chose is an arg-max of the uncached logits up to the bf16
+    tolerance."""
+    import numpy as np
+    from pixparse_amd.framework import DeviceEnv
+    from pixparse_amd.task import TaskFactory
+    from pixparse_amd.task.task_cruller_eval_docvqa import generate_string
+    _register_test_archs()
+    model_cfg = _cfg('vit_test', (37, 50), 'L', 2, 96)
+    rng = np.random.RandomState(2)
+    torch.manual_seed(9)
+    task, _ = TaskFactory.create_task('cruller_eval_docvqa', dict(model=model_cfg, dtype='bfloat16'), DeviceEnv(), None)
+    with torch.no_grad():
+        for n, p in task.model.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(4.0)
+    task.setup()
+    items = [{'image': rng.randint(0, 256, (60, 45)).astype(np.uint8), 'labels': {'question': q, 'answers': ['7', 'seven']}, 'image_id': i, 'question_id': i}
+             for i, q in enumerate(['how many?', 'total'])]
+    batch = task.collate_fn(items)
+    task.step(batch)
+    assert len(task.all_predictions) == 2 and task.all_ground_truths == [['7', 'seven']] * 2
+    anls = task.average_metrics({})['ANLS']
+    assert 0.0 <= anls <= 1.0 and task.gen_stats['prefills'] >= 2
+    # cached loop vs the reference-style uncached re-forward on one sample, 6 tokens
+    tok, model = task.tokenizer.trunk, task.model
+    enc = model.image_encoder(batch['images'][:1].to(dev)).clone()
+    prompt = '<s_docvqa><s_question>how many?</s_question><s_answer>'
+    text = generate_string(model, task.tokenizer, enc, prompt, dev, max_steps=6)
+    gen = tok.encode(text, add_special_tokens=False)
+    ids = tok.encode(prompt, add_special_tokens=False)
+    assert gen[:len(ids)] == ids and len(gen) > len(ids)
+    for t in range(len(ids), len(gen)):
+        inputs = model.text_decoder.prepare_inputs_for_inference(torch.tensor([gen[:t]], device=dev), enc, tok.pad_token_id)
+        ol = model.text_decoder(**inputs)['logits'][0, -1].float()
+        margin = float(ol.max() - ol[gen[t]])
+        assert margin <= 3e-2 * max(1.0, float(ol.abs().max())), (t, margin)
+    # CORD: one-token prompt, nTED / F1 bookkeeping on generated JSON
+    task, _ = TaskFactory.create_task('cruller_eval_cord', dict(model=model_cfg, dtype='bfloat16'), DeviceEnv(), None)
+    task.setup()
+    gts = [{'gt_parse': {'menu': [{'nm': 'cake', 'cnt': '2'}], 'total': {'total_price': '9'}}}, {'gt_parse': {'menu': {'nm': 'tea'}}}]
+    batch = task.collate_fn([{'image': rng.randint(0, 256, (60, 45)).astype(np.uint8), 'ground_truth': repr(g)} for g in gts])
+    m = task.step(batch)
+    assert 0.0 <= m['batch_accuracy'] <= 1.0 and len(task.acc_list) == 2
+    avg = task.average_metrics({0: m})
+    assert set(avg) == {'average_accuracy', 'f1_score'} and 0.0 <= avg['f1_score'] <= 1.0
+
+
 def test_bench_json_contract(dev, capsys, monkeypatch):
     """bench.py prints ONE JSON line with the driver's keys + roofline (live) on a small config, in-process"""
     import importlib, sys as _sys
