@@ -268,6 +268,7 @@ def main():
     ap.add_argument('--occupy-cus', type=int, default=0, help='measurement aid: N CUs held by a sleeping side-stream kernel during the timed '
                     'steps (single-GPU stand-in for the CUs RCCL takes in a data-parallel run); the line says so in `disturbance`')
     ap.add_argument('--gemm-schedule', choices=['dynamic', 'static'], default='dynamic', help='tile schedule of the persistent GEMMs (A/B)')
+    ap.add_argument('--graph-step', choices=['auto', 'on', 'off'], default='auto', help='replay the micro-step from a hipGraph (auto: models under 250 M parameters)')
     ap.add_argument('--reserved-cus', type=int, default=0, help='persistent GEMMs launch on 256 - N CUs (A/B with --occupy-cus)')
     args = ap.parse_args()
 
@@ -283,7 +284,8 @@ def main():
     from pixparse_amd.tokenizers import BYTE_TOKENIZER, TokenizerCfg
     cfg = TaskCrullerPretrainCfg(model_name=args.model, dtype='bfloat16', num_intervals=30, num_warmup_intervals=1, eval_frequency=10 ** 9,
                                  opt=OptimizationCfg(learning_rate=3e-4, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm'),
-                                 tokenizer=TokenizerCfg(name=BYTE_TOKENIZER))   # synthetic token ids: only vocab size + special ids matter
+                                 tokenizer=TokenizerCfg(name=BYTE_TOKENIZER),   # synthetic token ids: only vocab size + special ids matter
+                                 graph_step={'auto': None, 'on': True, 'off': False}[args.graph_step])
     cfg.model.image_encoder.pretrained = False    # random-init weights of the named architecture (no checkpoints offline): stated in `data`
     cfg.model.text_decoder.pretrained = False
     task = TaskCrullerPretrain(cfg, env)
@@ -369,6 +371,7 @@ def main():
         'step_mfma_frac': round(step_tflops / PEAK_BF16_TFLOPS, 4), 'step_tflops_per_gpu': round(step_tflops, 1),
         'activation_gb': round(m.activation_bytes() / 2 ** 30, 2),
         'collectives': 'rccl' if env.distributed else 'none',
+        'launch': 'hipGraph replay of the micro-step' if getattr(task, '_graph_on', False) else 'eager launches',
     }
     if host is not None:
         out['host_inputs'] = host

@@ -237,10 +237,18 @@ int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, float grad_d
                          float backoff_factor, int growth_interval, float* state, void* ws, void* stream);
 /* p,m,v updated in place with g*state[1]; skipped entirely when state[2] != 0 (GradScaler.step);
  * p_bf16 (optional) receives the bf16 shadow of the new p; g is zeroed when zero_grad != 0.
- * step >= 1: bias corrections 1 - beta^step from the host's count; step == 0: from state[3], the device-side count of
- * steps actually taken (advanced by crl_grad_norm* only when the step is not skipped); in that mode (8-float state) a
- * positive state[6] clamps every unscaled gradient element to [-state[6], state[6]] first (torch clip_grad_value_,
- * timm dispatch_clip_grad mode 'value'). */
+ * step >= 1: bias corrections 1 - beta^step from the host's count; step == 0 (device-side mode, state: 16 floats): bias
+ * corrections from state[9], state[10] and -- when lr < 0 -- the learning rate from state[8], all three written by
+ * crl_optim_prepare; in that mode a positive state[6] clamps every unscaled gradient element to [-state[6], state[6]]
+ * first (torch clip_grad_value_, timm dispatch_clip_grad mode 'value').
+ * crl_optim_prepare (one thread, between crl_grad_norm* and crl_adamw): what the host would otherwise compute per step and
+ * pass by value, so that every launch of a train step has identical arguments step after step and the whole step can be
+ * replayed from a hipGraph -- state[8] = learning rate of this update = timm CosineLRScheduler(t_initial, lr_min,
+ * warmup_t, warmup_lr_init) at u = state[7] updates attempted so far (ref task_cruller_pretrain.py:214-224,292-295;
+ * t_initial <= 0: constant base_lr), state[9] = 1 - beta1^t and state[10] = 1 / sqrt(1 - beta2^t) in double precision with
+ * t = state[3] (steps actually taken, this one included), then state[7] += 1. */
+int crl_optim_prepare(float* state, float base_lr, float warmup_lr_init, float lr_min, int warmup_t, int t_initial,
+                      float beta1, float beta2, void* stream);
 int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int step, const float* state, int zero_grad,
               void* stream);

@@ -148,6 +148,31 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
   }
 }
 
+// One thread: what the host used to compute per step and pass as launch arguments (learning rate, bias corrections), computed on the
+// device so that every launch of a train step has the same arguments from step to step (the step can be replayed from a hipGraph):
+//   state[8]  = learning rate of this update = timm CosineLRScheduler closed form at u = updates attempted so far (state[7]):
+//               u < warmup_t: warmup_lr_init + u (base - warmup_lr_init) / warmup_t;  u < t_initial: lr_min + (base - lr_min)(1 + cos(pi u / t_initial)) / 2;
+//               else lr_min;   t_initial <= 0: constant base_lr
+//   state[9]  = 1 - beta1^t,  state[10] = 1 / sqrt(1 - beta2^t)   with t = state[3] = steps taken including this one (double precision:
+//               1 - beta2^t cancels badly in fp32 for small t)
+//   state[7] += 1
+__global__ void optim_prepare_kernel(float* __restrict__ state, float base_lr, float warmup_lr_init, float lr_min, int warmup_t, int t_initial,
+                                     float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double u = (double)state[7];
+  double lr = (double)base_lr;
+  if (t_initial > 0) {
+    if (u < (double)warmup_t) lr = (double)warmup_lr_init + u * ((double)base_lr - (double)warmup_lr_init) / (double)warmup_t;
+    else if (u < (double)t_initial) lr = (double)lr_min + 0.5 * ((double)base_lr - (double)lr_min) * (1.0 + cos(3.14159265358979323846 * u / (double)t_initial));
+    else lr = (double)lr_min;
+  }
+  const double t = fmax((double)state[3], 1.0);
+  state[8] = (float)lr;
+  state[9] = (float)(1.0 - pow((double)beta1, t));
+  state[10] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+  state[7] = (float)(u + 1.0);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, u16* __restrict__ pb, size_t n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float rsqrt_bc2,
@@ -159,10 +184,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   // clip-by-value (timm dispatch_clip_grad mode 'value' = torch clip_grad_value_): |g| <= state[6] after unscaling; only with the
   // 8-float device state of the task's optimiser (dev_step), 0 = off
   const float cv = (dev_step && state[6] > 0.f) ? state[6] : INFINITY;
-  if (dev_step && !skip) {               // bias corrections from the device-side count of steps taken (this one included)
-    const float t = state[3];
-    bc1 = 1.f - __builtin_amdgcn_exp2f(t * __builtin_amdgcn_logf(b1));
-    rsqrt_bc2 = __builtin_amdgcn_rsqf(1.f - __builtin_amdgcn_exp2f(t * __builtin_amdgcn_logf(b2)));
+  if (dev_step) {                        // bias corrections (and, for lr < 0, the learning rate) prepared on the device by crl_optim_prepare
+    bc1 = state[9];
+    rsqrt_bc2 = state[10];
+    if (lr < 0.f) lr = state[8];
   }
   if (i + 3 < n) {
     float4 pv = *reinterpret_cast<float4*>(p + i);
@@ -245,9 +270,18 @@ extern "C" int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, f
   return 0;
 }
 
+extern "C" int crl_optim_prepare(float* state, float base_lr, float warmup_lr_init, float lr_min, int warmup_t, int t_initial,
+                                 float beta1, float beta2, void* stream) {
+  CRL_CHECK(state && base_lr >= 0.f && warmup_t >= 0 && beta1 > 0.f && beta1 < 1.f && beta2 > 0.f && beta2 < 1.f, "crl_optim_prepare: bad arguments");
+  optim_prepare_kernel<<<1, 64, 0, as_stream(stream)>>>(state, base_lr, warmup_lr_init, lr_min, warmup_t, t_initial, beta1, beta2);
+  CRL_LAUNCH_CHECK("crl_optim_prepare");
+  return 0;
+}
+
 extern "C" int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, const float* state, int zero_grad, void* stream) {
-  CRL_CHECK(n > 0 && p && g && m && v && (step >= 1 || (step == 0 && state)), "crl_adamw: bad args (step >= 1, or step == 0 with the device-side counter in state[3])");
+  CRL_CHECK(n > 0 && p && g && m && v && (step >= 1 || (step == 0 && state)), "crl_adamw: bad args (step >= 1, or step == 0 with the device-side state prepared by crl_optim_prepare)");
+  CRL_CHECK(lr >= 0.f || step == 0, "crl_adamw: lr < 0 (= read it from state[8]) needs the device-side mode (step == 0)");
   CRL_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0, "crl_adamw: arenas must be 16-byte aligned");
   const int hs = step >= 1 ? step : 1;
   const double bc1 = 1.0 - pow((double)beta1, hs), bc2 = 1.0 - pow((double)beta2, hs);

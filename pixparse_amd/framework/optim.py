@@ -15,8 +15,9 @@ import torch
 from .. import ops
 
 
-STATE_FLOATS = 8   # [0] grad norm, [1] clip * unscale coefficient, [2] found inf/nan, [3] optimiser steps TAKEN,
-                   # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6] clip-by-value threshold (0 = off), [7] unused   (include/crl.h)
+STATE_FLOATS = 16  # [0] grad norm, [1] clip * unscale coefficient, [2] found inf/nan, [3] optimiser steps TAKEN,
+                   # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6] clip-by-value threshold (0 = off), [7] updates ATTEMPTED
+                   # (the scheduler's clock), [8] learning rate of this update, [9] 1 - beta1^t, [10] 1 / sqrt(1 - beta2^t)   (include/crl.h)
 
 
 class ArenaAdamW:
@@ -30,6 +31,7 @@ class ArenaAdamW:
         arena.alloc_training_state()
         self.state = torch.zeros(STATE_FLOATS, dtype=torch.float32, device=arena.p.device)
         self.state[4] = 1.0   # no loss scaling until a LossScaler attaches
+        self.schedule = None  # (warmup_lr_init, lr_min, warmup_t, t_initial) of an attached CosineLRScheduler: the LR is then computed on the device
 
     def set_clip_value(self, value: Optional[float]):
         """timm dispatch_clip_grad mode 'value' (torch clip_grad_value_): clamp every unscaled gradient element to [-value, value]
@@ -56,7 +58,15 @@ class ArenaAdamW:
             ops.grad_norm_scaled(a.g, mx, grad_divisor, scaler.growth_factor, scaler.backoff_factor, scaler.growth_interval, self.state)
         else:
             ops.grad_norm(a.g, mx, (1.0 if inv_scale is None else inv_scale) / (grad_divisor if inv_scale is None else 1.0), self.state)
-        ops.adamw(a.p, a.g, a.m, a.v, a.pb, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0, self.state, zero_grad)
+        # learning rate + bias corrections on the device (crl_optim_prepare): no launch argument of the step changes from step to step.
+        # With a scheduler attached the LR follows its closed form from the device-side update counter (g['lr'] is the host's mirror of it,
+        # for logging); without one g['lr'] is passed as the constant rate.
+        if self.schedule is not None:
+            w0, lr_min, warmup_t, t_initial = self.schedule
+            ops.optim_prepare(self.state, g['initial_lr'], w0, lr_min, warmup_t, t_initial, g['betas'][0], g['betas'][1])
+        else:
+            ops.optim_prepare(self.state, g['lr'], 0.0, 0.0, 0, 0, g['betas'][0], g['betas'][1])
+        ops.adamw(a.p, a.g, a.m, a.v, a.pb, -1.0, g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0, self.state, zero_grad)
 
     def grad_norm(self) -> torch.Tensor:
         """device scalar: unscaled global L2 norm seen by the last step()"""
@@ -69,6 +79,10 @@ class ArenaAdamW:
     def state_dict(self):
         return dict(step=self.step_count, param_groups=[dict(g) for g in self.param_groups],
                     exp_avg=self.arena.m.clone(), exp_avg_sq=self.arena.v.clone())
+
+    def set_update_count(self, n: int):
+        """the scheduler's clock (updates attempted so far), e.g. after a resume"""
+        self.state[7] = float(n)
 
     def load_state_dict(self, sd):
         self.state[3] = float(sd['step'])
@@ -88,6 +102,8 @@ class CosineLRScheduler:
         self.optimizer = optimizer
         self.t_initial, self.warmup_t, self.warmup_lr_init, self.lr_min = t_initial, warmup_t, warmup_lr_init, lr_min
         self.base_values = [g['initial_lr'] for g in optimizer.param_groups]
+        if hasattr(optimizer, 'schedule'):      # ArenaAdamW evaluates the same closed form on the device (include/crl.h crl_optim_prepare)
+            optimizer.schedule = (float(warmup_lr_init), float(lr_min), int(warmup_t), int(t_initial))
 
     def _get_lr(self, t: int):
         if t < self.warmup_t:
@@ -97,6 +113,8 @@ class CosineLRScheduler:
         return [self.lr_min for _ in self.base_values]
 
     def step_update(self, num_updates: int, metric=None):
+        """host mirror of the rate the next update will use (logging, get_current_lr); the device clock advances by itself with every
+        update -- after a resume call optimizer.set_update_count(num_updates) as well"""
         for g, lr in zip(self.optimizer.param_groups, self._get_lr(num_updates)):
             g['lr'] = lr
 
@@ -123,7 +141,7 @@ class LossScaler:
 
     def attach(self, state: torch.Tensor):
         """bind to the optimiser's state vector (>= 8 floats); the current scale / tracker move there"""
-        assert state.numel() >= 8
+        assert state.numel() >= 16
         state[4] = self._host[0]
         state[5] = self._host[1]
         self._state = state

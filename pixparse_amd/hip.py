@@ -57,6 +57,7 @@ SIGNATURES = {
     'crl_grad_norm_ws_bytes': (Z, []),
     'crl_grad_norm': (I, [P, L, F, F, P, P, P]),
     'crl_grad_norm_scaled': (I, [P, L, F, F, F, F, I, P, P, P]),
+    'crl_optim_prepare': (I, [P, F, F, F, I, I, F, F, P]),
     'crl_adamw': (I, [P, P, P, P, P, L, F, F, F, F, F, I, P, I, P]),
     'crl_cast_bf16': (I, [P, P, L, P]),
     'crl_cast_pad_bf16': (I, [P, P, L, L, L, P]),

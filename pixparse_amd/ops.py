@@ -245,8 +245,16 @@ def grad_norm_scaled(g, max_norm: float, grad_divisor: float, growth_factor: flo
              int(growth_interval), _p(state), _p(ws), _stream())
 
 
+def optim_prepare(state, base_lr: float, warmup_lr_init: float, lr_min: float, warmup_t: int, t_initial: int, beta1: float, beta2: float) -> None:
+    """device-side learning rate (state[8], cosine + warm-up at state[7] updates; t_initial <= 0: constant) and bias corrections (state[9], [10])"""
+    assert state.numel() >= 16
+    hip.call('crl_optim_prepare', _p(state), float(base_lr), float(warmup_lr_init), float(lr_min), int(warmup_t), int(t_initial),
+             float(beta1), float(beta2), _stream())
+
+
 def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step: int, state, zero_grad: bool) -> None:
-    """step >= 1: host-side step number; step == 0: the device-side count of steps taken in state[3]"""
+    """step >= 1: host-side step number; step == 0: device-side mode (bias corrections, and the learning rate when lr < 0, from the
+    state words written by optim_prepare)"""
     hip.call('crl_adamw', _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
              float(eps), float(weight_decay), int(step), _p(state), int(zero_grad), _stream())
 

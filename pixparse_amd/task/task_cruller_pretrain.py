@@ -32,6 +32,11 @@ class TaskCrullerPretrainCfg(TaskTrainCfg):
     # not a reference field: the reference's decoder drops hidden states (p = 0.1) exactly when it was built with pretrained=False
     # (from_config leaves train mode); here that behaviour is an explicit switch, off by default
     decoder_dropout: bool = False
+    # not a reference field: replay the whole micro-step (forward, CE, backward, optimiser tail) from a hipGraph captured on the second
+    # step of each kind.  None = automatic: on for single-process runs of launch-bound models (< 250 M parameters: cfg-1 / cfg-2 spend
+    # their step in hundreds of microsecond-scale launches), off when the step has host-visible state (dropout masks, RCCL buckets) or
+    # PIXPARSE_AMD_GRAPH_STEP=0 says so; PIXPARSE_AMD_GRAPH_STEP=1 forces it on where it is legal
+    graph_step: Optional[bool] = None
 
     def __post_init__(self):
         if self.model_name:
@@ -144,6 +149,19 @@ class TaskCrullerPretrain(TaskTrain):
                                            warmup_t=self.num_warmup_intervals * self.num_steps_per_interval,
                                            warmup_lr_init=opt.warmup_learning_rate)
         self.scheduler.step_update(0)
+        # hipGraph replay of the micro-step: legal when nothing the step launches depends on host state -- the LR and the bias
+        # corrections come from device words (crl_optim_prepare), the GradScaler lives on the device, batches are copied into static buffers
+        import os
+        want = self.cfg.graph_step
+        env = os.environ.get('PIXPARSE_AMD_GRAPH_STEP')
+        if want is None:
+            want = (env == '1') or (env != '0' and self.model.arena.total < 250_000_000)
+        legal = not self.reducer.active and getattr(self.model, '_drop', None) is None
+        if want and not legal and (self.cfg.graph_step or env == '1'):
+            _logger.warning('graph_step requested but the step has host-visible state (data-parallel buckets or dropout masks): running eagerly')
+        self._graph_on = bool(want and legal)
+        self._graphs = {}          # need_update -> 'warm' | torch.cuda.CUDAGraph
+        self._graph_in = None      # static input buffers (image, shifted tokens, shifted targets)
 
     def train_interval_start(self):
         self.optimizer.zero_grad()
@@ -174,6 +192,40 @@ class TaskCrullerPretrain(TaskTrain):
                                 grad_divisor=self.reducer.grad_divisor())
             self.model.refresh_shadows(full=False)
 
+    def _graphed_micro_step(self, image_input, text_input, text_target, need_update: bool):
+        """forward + CE + backward (+ optimiser tail on update steps) replayed from a hipGraph.  The batch is copied into static device
+        buffers; the first micro-step of each kind (with / without the optimiser tail) runs eagerly (it sizes every activation buffer
+        and scratch), the second is captured and replayed, all later ones are replays.  Same kernels, same arguments, same order as the
+        eager step: losses and parameters are bit-identical (tests/test_model_gpu.py::test_graphed_train_step_equals_eager)."""
+        shapes = (tuple(image_input.shape), tuple(text_input.shape), tuple(text_target.shape))
+        if self._graph_in is None:
+            dev = self.device_env.device
+            self._graph_in = (torch.empty(shapes[0], dtype=torch.float32, device=dev), torch.empty(shapes[1], dtype=text_input.dtype, device=dev),
+                              torch.empty(shapes[2], dtype=text_target.dtype, device=dev))
+        gi, gt, gy = self._graph_in
+        if shapes != (tuple(gi.shape), tuple(gt.shape), tuple(gy.shape)):      # a ragged last batch: run it eagerly
+            loss = self.forward(image_input, text_input, text_target)
+            self._backward(need_update)
+            return loss
+        gi.copy_(image_input, non_blocking=True)
+        gt.copy_(text_input, non_blocking=True)
+        gy.copy_(text_target, non_blocking=True)
+        st = self._graphs.get(need_update)
+        if st is None:
+            loss = self.forward(gi, gt, gy)
+            self._backward(need_update)
+            self._graphs[need_update] = 'warm'
+            return loss
+        if st == 'warm':
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.forward(gi, gt, gy)
+                self._backward(need_update)
+            self._graphs[need_update] = st = graph
+        st.replay()
+        return self.model._loss
+
     log_phase_name = 'train'
 
     def train_step(self, sample):
@@ -190,8 +242,11 @@ class TaskCrullerPretrain(TaskTrain):
 
         accum_steps = self.cfg.opt.grad_accum_steps
         need_update = (self.interval_batch_idx + 1) % accum_steps == 0
-        loss = self.forward(image_input, text_input, text_target)
-        self._backward(need_update)
+        if getattr(self, '_graph_on', False):
+            loss = self._graphed_micro_step(image_input, text_input, text_target, need_update)
+        else:
+            loss = self.forward(image_input, text_input, text_target)
+            self._backward(need_update)
         self.last_loss = loss
 
         self.batch_idx += 1
@@ -237,6 +292,7 @@ class TaskCrullerPretrain(TaskTrain):
         for k, v in sd.get('counters', {}).items():
             setattr(self, k, v)
         self.scheduler.step_update(self.step)
+        self.optimizer.set_update_count(self.step)        # the device-side clock of the LR schedule
 
     def __repr__(self):
         return '\n'.join([f'model: {self.model.cfg}', f'opt: {repr(self.optimizer)}', f'sched: {repr(self.scheduler)}'])

@@ -155,7 +155,10 @@ def test_no_cpu_fallback():
     with pytest.raises(ValueError):
         TaskFactory.create_task('nope', {}, DeviceEnv('cpu'), None)
     with pytest.raises(NotImplementedError):
-        TaskFactory.create_task('cruller_eval_docvqa', {}, DeviceEnv('cpu'), None)   # in the reference's registry, not built here
+        TaskFactory.create_task('donut_eval_ocr', {}, DeviceEnv('cpu'), None)   # in the reference's registry, not built here
+    task, _ = TaskFactory.create_task('cruller_eval_docvqa', dict(model=get_model_config('cruller_small')), DeviceEnv('cpu'), None)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        task.setup()                                                             # eval tasks refuse a CPU device as loudly as the train task
 
 
 def test_decoder_dropout_switch_cpu():

@@ -7,6 +7,8 @@ the LOSS must agree to 1e-3 relative (BASELINE.json north_star) -- asserted belo
 import json
 import os
 
+import math
+
 import pytest
 import torch
 from safetensors.torch import load_file
@@ -409,6 +411,50 @@ def test_greedy_generation_with_kv_cache_vs_oracle(dev, enc, img, fmt, B):
     assert torch.equal(g_ids, e_ids) and torch.equal(e_ids, ids)
     texts = generate_ocr(model, Tok, enc_out, env, 5, '<s_pretrain>')
     assert len(texts) == B and all(t.startswith('<s_pretrain>') for t in texts)
+
+
+@pytest.mark.parametrize('accum', [1, 2])
+def test_graphed_train_step_equals_eager(dev, accum):
+    """TaskCrullerPretrainCfg.graph_step: the micro-step (forward, CE, backward, clip / AdamW / zero_grad) replayed from a hipGraph is the
+    eager step bit for bit -- 8 micro-steps with warm-up cosine LR (device-side schedule, crl_optim_prepare), clip-norm and grad
+    accumulation 1 / 2 (two graphs: with and without the optimiser tail): identical losses, gradient norms, learning rates taken from
+    the device words, and final parameters / AdamW moments"""
+    from pixparse_amd.data import synthetic_batch
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    _register_test_archs()
+    L, layers, img = 24, 2, (37, 50)
+
+    def run(graph):
+        cfg = TaskCrullerPretrainCfg(num_intervals=2, num_warmup_intervals=1, eval_frequency=1000, dtype='bfloat16', graph_step=graph,
+                                     opt=OptimizationCfg(learning_rate=1e-3, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm',
+                                                         grad_accum_steps=accum),
+                                     model=_cfg('vit_test', img, 'RGB', layers, L))
+        torch.manual_seed(3)
+        task = TaskCrullerPretrain(cfg, DeviceEnv())
+        task.train_setup(num_batches_per_interval=4)
+        task.train_interval_start()
+        assert task._graph_on == graph
+        rec = []
+        for i in range(8):
+            task.train_step(synthetic_batch(2, 3, img, L, task.vocab_size, seed=60 + i, ragged=True))
+            st = task.optimizer.state.cpu()
+            rec.append((float(task.last_loss), float(st[0]), float(st[8]), float(st[3]), float(st[7]), task.get_current_lr()))
+        kinds = {k: type(v).__name__ for k, v in task._graphs.items()}
+        ar = task.model.arena
+        return rec, ar.p.clone(), ar.m.clone(), ar.v.clone(), kinds
+    eager, pe, me, ve, _ = run(False)
+    graph, pg, mg, vg, kinds = run(True)
+    assert kinds == ({True: 'CUDAGraph'} if accum == 1 else {True: 'CUDAGraph', False: 'CUDAGraph'})
+    assert eager == graph, list(zip(eager, graph))
+    assert torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg)
+    # the device-side LR is the scheduler's closed form: host mirror (set AFTER the update, for the next one) vs the device word of the update
+    n_upd = 8 // accum
+    assert eager[-1][3] == n_upd and eager[-1][4] == n_upd
+    lrs = [r[2] for r in eager[accum - 1::accum]]
+    w, t = 4 // accum, 8 // accum          # one warm-up interval, two intervals in all, 4 // accum updates per interval
+    want = [1e-3 * u / w if u < w else 0.5 * 1e-3 * (1 + math.cos(math.pi * u / t)) if u < t else 0.0 for u in range(n_upd)]
+    assert all(abs(a - b) <= 1e-9 + 1e-6 * b for a, b in zip(lrs, want)), (lrs, want)
 
 
 def test_greedy_generation_with_prompt_prefill_vs_oracle(dev):
