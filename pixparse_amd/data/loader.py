@@ -199,6 +199,18 @@ class _DocShards(IterableDataset):
         nw, wid = (wi.num_workers, wi.id) if wi is not None else (1, 0)
         reader, n_readers = self.global_rank * nw + wid, self.world_size * nw
         rng = random.Random(self.seed + 1000003 * self.interval + reader)
+        if not self.is_train:
+            # evaluation: every reader walks its part ONCE and emits all of it, the last (partial) batch included -- no quota, so no
+            # sample is dropped whatever the worker count (100 samples, batch 8, 4 workers: 4 x (3 full + 1 partial) batches)
+            batch = []
+            for s in self._samples(reader, n_readers, rng):
+                batch.append(s)
+                if len(batch) == self.batch_size:
+                    yield self.collate_fn(batch)
+                    batch = []
+            if batch:
+                yield self.collate_fn(batch)
+            return
         quota = self.num_batches // nw + (1 if wid < self.num_batches % nw else 0)     # batches this worker contributes
         made, batch, passes = 0, [], 0
         while made < quota:
@@ -213,10 +225,6 @@ class _DocShards(IterableDataset):
                     if made >= quota:
                         return
             passes += 1
-            if not self.is_train:
-                if batch:
-                    yield self.collate_fn(batch)
-                return
             if not got:
                 raise RuntimeError(f'reader {reader}: no usable sample in {self.shards}')
             # training: the interval length is num_samples, shards are re-read (reshuffled by the rng) until it is reached
@@ -230,6 +238,18 @@ class _IntervalLoader:
         pin = torch.cuda.is_available() and not device_stage
         self.dl = DataLoader(dataset, batch_size=None, num_workers=num_workers, pin_memory=pin,
                              persistent_workers=False, prefetch_factor=2 if num_workers > 0 else None)
+        self._pinned = []          # one reusable pinned staging buffer per batch slot (on-device preprocessing): no hipHostMalloc per page
+        self._staged = None        # event recorded after the last batch's uploads were enqueued
+
+    def _stage(self, i: int, pg: torch.Tensor) -> torch.Tensor:
+        n = pg.numel()
+        while len(self._pinned) <= i:
+            self._pinned.append(None)
+        if self._pinned[i] is None or self._pinned[i].numel() < n:
+            self._pinned[i] = torch.empty(int(n * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        view = self._pinned[i][:n].view(pg.shape)
+        view.copy_(pg)
+        return view
 
     def set_interval(self, interval: int):
         self.dataset.interval = interval
@@ -240,15 +260,19 @@ class _IntervalLoader:
     def __iter__(self):
         n = 0
         for batch in self.dl:
-            if n >= self.dataset.num_batches:
+            if self.dataset.is_train and n >= self.dataset.num_batches:     # evaluation runs to exhaustion (partial tail batches included)
                 break
             n += 1
             if self.device_stage:
                 pages = batch[0]
                 pre = self.image_preprocess
                 out = torch.empty(len(pages), pre.C, pre.Ho, pre.Wo, dtype=torch.float32, device=pre.device)
+                if self._staged is not None:
+                    self._staged.synchronize()           # the previous batch's uploads have left the staging buffers
                 for i, pg in enumerate(pages):           # decoded uint8 page -> HIP resize + normalise, straight into the batch
-                    pre(pg.pin_memory() if pg.device.type == 'cpu' else pg, out=out[i])
+                    pre(self._stage(i, pg) if pg.device.type == 'cpu' else pg, out=out[i])
+                self._staged = torch.cuda.Event()
+                self._staged.record()
                 batch = (out,) + tuple(batch[1:])
             yield batch
 

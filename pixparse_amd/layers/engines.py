@@ -33,7 +33,8 @@ class Buffers:
         shape = tuple(int(s) for s in shape)
         t = self.t.get(name)
         if t is None or t.shape != shape or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            with torch.inference_mode(False):   # a buffer first sized inside an eval task's inference_mode() block must stay writable outside it
+                t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.t[name] = t
         return t
 

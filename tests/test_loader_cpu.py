@@ -118,6 +118,22 @@ def test_directory_source_equals_tar_source_and_eval_format(tmp_path):
     assert [len(t) for _, t, _ in out[0]] == [4, 4, 1]                     # eval keeps the ragged last batch
 
 
+def test_eval_with_workers_sees_every_sample_once(tmp_path):
+    """evaluation with several workers: every reader emits ALL of its part, the partial tail batch included (no per-worker batch
+    quota): 23 documents, batch 4, 3 workers -> all 23 documents, each exactly once"""
+    from pixparse_amd.data import DatasetCfg, create_loader
+    docs = _make_docs(23, seed=4)
+    _write_tar(str(tmp_path / 'e.tar'), docs)
+    img_pre, anno_pre, tok = _task_fns()
+    cfg = DatasetCfg(source=str(tmp_path / 'e.tar'), num_samples=23, batch_size=4, num_workers=3)
+    b = create_loader(cfg, is_train=False, image_preprocess=img_pre, anno_preprocess=anno_pre, image_fmt='L')
+    ids = []
+    for image, text, _ in b.loader:
+        assert image.shape[0] == len(text) <= 4
+        ids += [int(tok.decode(t[0].tolist(), skip_special_tokens=True).split()[1]) for t in text]
+    assert sorted(ids) == list(range(23))
+
+
 def test_ranks_and_workers_read_disjoint_samples(tmp_path):
     from pixparse_amd.data import DatasetCfg, create_loader
     docs = _make_docs(32, seed=2)
