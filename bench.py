@@ -86,7 +86,7 @@ def time_kernel(fn, iters=3):
 
 
 KERNEL_NAMES = ['attn_fwd_kernel<false>', 'attn_fwd_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
-                'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>']
+                'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>', 'attn_bwd_fused_kernel<0>', 'attn_dq_reduce_kernel']
 
 
 def collect_live_profile(steps):

@@ -128,14 +128,24 @@ int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, 
 int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
                  float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
-/* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators: the dQ
- * pass, which runs first, computes them from the dO / O rows it holds and stores them for the dK/dV pass).  dq/dk/dv strides as q/k/v. */
+/* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators).
+ * dq/dk/dv strides as q/k/v.  Two forms (same results up to bf16 rounding of dq; both deterministic, no float atomics):
+ *   two-pass    dQ pass (recomputes S, dP; produces the row constants) then dK/dV pass (recomputes S, dP): 7 MFMA products per tile;
+ *   single pass (non-causal, ws >= crl_attn_bwd_ws_bytes(...) > 0): one recomputation feeds dK, dV and dQ -- 5 products; a
+ *               workgroup owns 512 keys of a head, so dQ is a sum over the key blocks: every 256-key half writes its partial as a
+ *               bf16 [B, Nq, H*64] slab into ws and a reduce pass adds the ceil(Nk / 256) slabs in fixed order in fp32, applies
+ *               `scale` and rounds to dq.
+ * crl_attn_bwd_ws_bytes: 0 when the two-pass form will run.
+ * crl_attn_bwd_set_mode: 0 = auto = two-pass (measured faster on gfx950: the single pass is bound by LDS traffic, csrc/attention.hip),
+ *   1 = two-pass, 2 = single pass whenever legal (non-causal). */
+size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
+int crl_attn_bwd_set_mode(int mode);
 int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
                  void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
                  void* dv, int64_t dv_bs, int64_t dv_rs,
-                 int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
+                 int B, int H, int Nq, int Nk, float scale, int causal, void* ws, size_t ws_bytes, void* stream);
 
 /* Live per-kernel timing for bench.py's roofline object: between crl_prof_begin and crl_prof_end every launch of an
  * instrumented kernel is bracketed by HIP events on its own stream (pool of `capacity` pairs created up front, no
@@ -144,7 +154,9 @@ int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
 #define CRL_K_ATTN_FWD 0        /* attn_fwd_kernel<false>,      + 1 = <true> (causal) */
 #define CRL_K_ATTN_BWD_DKDV 2   /* attn_bwd_dkdv_kernel<false>, + 1 = <true> */
 #define CRL_K_ATTN_BWD_DQ 4     /* attn_bwd_dq_kernel<false>,   + 1 = <true> */
-#define CRL_K_COUNT 6
+#define CRL_K_ATTN_BWD_FUSED 6  /* attn_bwd_fused_kernel (single-pass backward; work = the whole algorithmic backward) */
+#define CRL_K_ATTN_DQ_REDUCE 7  /* attn_dq_reduce_kernel (sum of the partial-dQ slabs; no FLOPs credited) */
+#define CRL_K_COUNT 8
 /* Measurement aid (never on the product path): n_cus workgroups that each take a whole CU (all 160 KiB of its LDS) and sleep
  * until max_seconds (<= 120) have passed or *stop_flag (optional; device-visible, e.g. pinned host memory) becomes non-zero.
  * Stands in, on one GPU, for the CUs RCCL's all-reduce kernels hold while gradient buckets are in flight (bench.py

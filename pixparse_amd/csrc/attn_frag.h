@@ -74,6 +74,13 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// c += a.b with the accumulator TIED to the destination (asm: with 128 long-lived accumulator registers hipcc allocates the builtin's
+// destination apart from its C operand and spills).  hipcc does not see an MFMA here, so it inserts none of the wait states an
+// operand written by the preceding VALU instruction (v_cvt_pk_bf16_f32) may need: the s_nop in front supplies them; the accumulators
+// themselves are only read by further MFMAs (interlocked in hardware) until the kernel's epilogue, which settles the pipe first.
+__device__ __forceinline__ void mfma32_acc(bf16x8 a, bf16x8 b, f32x16& c) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 // row index (within a 32-row block) of accumulator register r for lane half hh
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

@@ -37,7 +37,9 @@ SIGNATURES = {
     'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, P, I, P, P]),
     'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, P]),
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
-                         I, I, I, I, F, I, P]),
+                         I, I, I, I, F, I, P, Z, P]),
+    'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
+    'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),
     'crl_debug_occupy_cus': (I, [I, ctypes.c_double, P, P]),
     'crl_prof_begin': (I, [I]),

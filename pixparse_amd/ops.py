@@ -98,6 +98,7 @@ class Scratch:
 
 _scratch = Scratch()
 _gemm_scratch = Scratch()
+_attn_scratch = Scratch()
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = True, n: Optional[int] = None) -> None:
@@ -174,9 +175,11 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, 
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)
+    wsb = hip.query('crl_attn_bwd_ws_bytes', B, heads, Nq, Nk, int(causal))     # partial-dQ slabs of the single-pass form (0: two-pass)
+    ws = _attn_scratch.get(wsb, q.device) if wsb else None
     hip.call('crl_attn_bwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o),
              _p(d_o), *_bs_rs(d_o), _p(lse), _p(delta), _p(dq), *_bs_rs(dq), _p(dk), *_bs_rs(dk), _p(dv), *_bs_rs(dv),
-             B, heads, Nq, Nk, float(scale), int(causal), _stream())
+             B, heads, Nq, Nk, float(scale), int(causal), _p(ws), wsb, _stream())
 
 
 def swin_attn_fwd(qkv, table, out, B, Hf, Wf, heads, w, shift, scale) -> None:
