@@ -35,6 +35,47 @@ def close(a, b, rtol, atol, what=''):
     assert not bad.any(), f'{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (ref max {float(b.abs().max()):.4g})'
 
 
+# ------------------------------------------------------------------------------------------- attention backward, single-pass form
+@pytest.mark.parametrize('B,H,Nq,Nk', [(1, 2, 300, 700), (2, 1, 64, 512), (1, 2, 100, 45), (1, 2, 1023, 1300)])
+def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
+    """crl_attn_bwd_set_mode(2): dK, dV and dQ from ONE recomputation of S / dP (5 MFMA products), dQ as a sum of per-key-block bf16 slabs
+    reduced in fixed order.  Against the default two-pass form: dK and dV bit for bit, dQ within the extra bf16 rounding of the partials;
+    against fp32 torch: the tolerance of the two-pass tests; two runs bit-identical.  Shapes cover a ragged last key block, fewer keys
+    than one workgroup owns (512), ragged query tiles and the cross-attention aspect ratio."""
+    from pixparse_amd import hip, ops
+    D, scale = H * 64, 0.125
+    g = torch.Generator(device=dev).manual_seed(Nq + Nk)
+    q, do = (torch.randn(B, Nq, D, generator=g, device=dev).to(BF16) for _ in range(2))
+    k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(BF16) for _ in range(2))
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Nq, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False)
+    delta = torch.empty(2, B, H, Nq, device=dev)
+
+    def bwd(mode):
+        dq, dk, dv = torch.full_like(q, float('nan')), torch.full_like(k, float('nan')), torch.full_like(v, float('nan'))
+        hip.call('crl_attn_bwd_set_mode', mode)
+        try:
+            assert (hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 0) > 0) == (mode == 2)
+            assert hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 1) == 0          # causal: always two-pass
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False)
+        finally:
+            hip.call('crl_attn_bwd_set_mode', 0)
+        return dq, dk, dv
+    dq2, dk2, dv2 = bwd(1)
+    dq1, dk1, dv1 = bwd(2)
+    assert torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert rel(dq1, dq2) < 1e-2
+    hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2).requires_grad_(True)
+    Q, K, V = hd(q), hd(k), hd(v)
+    (torch.softmax(Q @ K.transpose(-1, -2) * scale, -1) @ V).backward(do.float().reshape(B, Nq, H, 64).transpose(1, 2))
+    back = lambda t: t.transpose(1, 2).reshape(B, -1, D)
+    assert rel(dq1, back(Q.grad)) < 2e-2 and rel(dk1, back(K.grad)) < 2e-2 and rel(dv1, back(V.grad)) < 2e-2
+    dq3, dk3, dv3 = bwd(2)
+    assert torch.equal(dq3, dq1) and torch.equal(dk3, dk1) and torch.equal(dv3, dv1)
+
+
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(300, 264, 192), (129, 128, 64), (1000, 520, 96), (64, 8, 32), (257, 1024, 1024)])
 def test_gemm_nt_epilogues(dev, M, N, K):
