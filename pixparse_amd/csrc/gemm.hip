@@ -298,14 +298,21 @@ static int64_t quant_rows(int layout, int64_t M, int64_t N) {
 #ifndef G_REM_SPLIT
 #define G_REM_SPLIT 1
 #endif
-static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K) {
+static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap = 8) {
   if (!G_REM_SPLIT || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
   const int64_t nk = K / 64, tiles = ((rem + 127) / 128) * ((N + 127) / 128);
   if (nk < 32 || tiles >= 128) return 1;
   int ns = (int)(384 / tiles);
-  if (ns > 8) ns = 8;
+  if (ns > cap) ns = cap;
   while (ns > 1 && nk / ns < 8) --ns;
   return ns;
+}
+// The same treatment for a WHOLE forward / dgrad GEMM with few output tiles and a very long contraction -- the LM-head dgrad of a small
+// batch: [254, 50304] x [50304, 768] = 12 tiles of 128 x 128 walking 786 K tiles each on 12 of 256 CUs (cfg-1: 0.4 ms of a 7 ms step).
+// Up to 32 chunks of the contraction as fp32 slabs + the reduce that applies the epilogue.
+static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
+  if (layout == CRL_TN || K < 64 * 128) return 1;
+  return rem_split(epilogue, M, N, K, 32);
 }
 
 extern "C" int crl_gemm_set_policy(int policy) {
@@ -317,6 +324,10 @@ extern "C" int crl_gemm_set_policy(int policy) {
 extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
   const Plan p = plan_gemm(layout, epilogue, M, N, K, true);
   if (p.nsplit > 1) return (size_t)p.nsplit * M * N * sizeof(float);
+  if (!p.big && g_policy == 0) {
+    const int ns = few_tiles_split(layout, epilogue, M, N, K);
+    if (ns > 1) return (size_t)ns * M * N * sizeof(float);
+  }
   if (p.big && g_policy != 3) {
     const int64_t r = quant_rows(layout, M, N);
     if (r > 0) {
@@ -429,6 +440,24 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     switch (layout) {
       case CRL_NT: return launch_epi<CRL_NT>(rest, epilogue, 64, 1, s);
       default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, s);
+    }
+  }
+  if (g_policy == 0 && bk == 64) {
+    const int ns = few_tiles_split(layout, epilogue, M, N, K);
+    if (ns > 1 && ws && ws_bytes >= (size_t)ns * M * N * sizeof(float)) {
+      GemmArgs sl = a;
+      sl.bias = nullptr; sl.aux = nullptr; sl.resid = nullptr;
+      sl.C = ws; sl.ldc = (int)N; sl.slab_stride = (size_t)M * N;
+      sl.kchunk = (int)((K / 64 + ns - 1) / ns);
+      const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
+      if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
+      const unsigned blocks = (unsigned)(((size_t)M * N / 4 + 255) / 256);
+      if (epilogue == CRL_EPI_BF16)
+        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, nullptr, 0);
+      else
+        splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, a.resid, (int)ldr);
+      CRL_LAUNCH_CHECK("crl_gemm_bf16(few-tiles split reduce)");
+      return 0;
     }
   }
   switch (layout) {

@@ -348,6 +348,27 @@ def test_gemm_remainder_rows_split_contraction(dev):
         close(out, x.float() @ w2.float(), 1e-2, 2e-2, 'remainder split NN')
 
 
+def test_gemm_few_tiles_long_contraction_split(dev):
+    """a forward / dgrad GEMM with a handful of output tiles and a very long contraction (the LM-head dgrad of a small batch: 254 x 768 over
+    K = 50304) is cut into up to 32 chunks of the contraction (fp32 slabs + the reduce that applies the epilogue)"""
+    from pixparse_amd import hip, ops
+    M, N, K = 254, 768, 50304
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, K) == 32 * M * N * 4
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 4096) == 0          # short contraction: one launch
+    dy = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((K, N), dev, 0.02, 2, BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_dgrad(dy, w, out)
+    close(out, dy.float() @ w.float(), 1e-2, 3e-2, 'few-tiles split NN')
+    x = rnd((M, 8192), dev, 1.0, 3, BF16)
+    w2 = rnd((256, 8192), dev, 0.02, 4, BF16)
+    bias = rnd((256,), dev, 0.5, 5)
+    y = rnd((M, 256), dev, 1.0, 6)
+    want = y + (x.float() @ w2.float().t() + bias.to(BF16).float()).to(BF16).float()
+    ops.linear_fwd(x, w2, bias, y, ops.EPI_F32_RESID, resid=y)
+    close(y, want, 1e-2, 3e-2, 'few-tiles split NT + residual')
+
+
 def test_gemm_256_splitk_wgrad(dev):
     from pixparse_amd import hip, ops
     Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
