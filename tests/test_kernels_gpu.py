@@ -39,7 +39,7 @@ def close(a, b, rtol, atol, what=''):
 @pytest.mark.parametrize('B,H,Nq,Nk', [(1, 2, 300, 700), (2, 1, 64, 512), (1, 2, 100, 45), (1, 2, 1023, 1300)])
 def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
     """crl_attn_bwd_set_mode(2): dK, dV and dQ from ONE recomputation of S / dP (5 MFMA products), dQ as a sum of per-key-block bf16 slabs
-    reduced in fixed order.  Against the default two-pass form: dK and dV bit for bit, dQ within the extra bf16 rounding of the partials;
+    reduced in fixed order.  Against the default two-pass form: dV bit for bit, dK to 1e-4, dQ within the extra bf16 rounding of the partials;
     against fp32 torch: the tolerance of the two-pass tests; two runs bit-identical.  Shapes cover a ragged last key block, fewer keys
     than one workgroup owns (512), ragged query tiles and the cross-attention aspect ratio."""
     from pixparse_amd import hip, ops
@@ -64,8 +64,10 @@ def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
         return dq, dk, dv
     dq2, dk2, dv2 = bwd(1)
     dq1, dk1, dv1 = bwd(2)
-    assert torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    # dV bit for bit (P does not depend on the row constants); dK up to the summation order of delta = rowsum(dO o O), which the two
+    # forms compute in different kernels (a last-bit difference in delta flips a bf16 rounding of dS here and there)
+    assert torch.equal(dv1, dv2) and rel(dk1, dk2) < 1e-4
     assert rel(dq1, dq2) < 1e-2
     hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2).requires_grad_(True)
     Q, K, V = hd(q), hd(k), hd(v)
