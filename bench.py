@@ -382,7 +382,8 @@ def main():
         if live_prof is not None:
             out['roofline'] = live_prof
             # the dominant symbol also serves the decoder's cross-attention; traffic is quoted for the encoder-shape launches only
-            # (grid = tiles x B x H workgroups of 256 threads) next to that shape's algorithmic bytes (each operand once)
+            # (shape key of scripts/pmc_traffic.py: grid = query tiles x B x H workgroups of 256 threads -- for the dK/dV pass the grid of
+            # the dQ pass launched right before it) next to that shape's algorithmic bytes (each operand once)
             grid, algo = None, None
             if m.enc_kind == 'vit' and live_prof['kernel'].endswith('<false>'):
                 enc_ = m._engines[0]

@@ -41,20 +41,31 @@ def short(name):
     return out.strip()
 
 
+# kernels whose grid does not tell their launch shapes apart, and the kernel launched right before them in the same crl_* call whose
+# grid does: the dK/dV pass has one workgroup per 128 KEYS (6189 encoder keys for the ViT self-attention and for the decoder's
+# cross-attention alike); the dQ pass that precedes it has one per 128 QUERIES (6189 vs 1023)
+SHAPE_PARTNER = {'attn_bwd_dkdv_kernel<false>': 'attn_bwd_dq_kernel<false>', 'attn_bwd_dkdv_kernel<true>': 'attn_bwd_dq_kernel<true>'}
+
+
 def read_pass(d, counter):
-    """{(kernel, grid size in threads): (mean counter value, launches)}; grid None = all launches of the symbol"""
+    """{(kernel, shape key): (mean counter value, launches)}; shape key None = all launches of the symbol, otherwise the grid size in
+    threads of the launch (of its SHAPE_PARTNER for the kernels listed there)"""
     sums, cnt = defaultdict(float), defaultdict(int)
     files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
     assert files, f'no counter_collection.csv under {d}'
     for f in files:
         with open(f, newline='') as fh:
-            for row in csv.DictReader(fh):
-                if row['Counter_Name'] != counter:
-                    continue
-                k = short(row['Kernel_Name'])
-                for key in ((k, None), (k, int(row.get('Grid_Size', 0) or 0))):
-                    sums[key] += float(row['Counter_Value'])
-                    cnt[key] += 1
+            rows = [r for r in csv.DictReader(fh) if r['Counter_Name'] == counter]
+        rows.sort(key=lambda r: int(r.get('Dispatch_Id', 0) or 0))
+        last_grid = {}
+        for row in rows:
+            k = short(row['Kernel_Name'])
+            grid = int(row.get('Grid_Size', 0) or 0)
+            last_grid[k] = grid
+            shape = last_grid.get(SHAPE_PARTNER[k], grid) if k in SHAPE_PARTNER else grid
+            for key in ((k, None), (k, shape)):
+                sums[key] += float(row['Counter_Value'])
+                cnt[key] += 1
     return {k: (sums[k] / cnt[k], cnt[k]) for k in sums}
 
 
