@@ -127,7 +127,8 @@ int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, 
  * diagonal bottom-right (key j visible to query i iff j <= i + Nk - Nq). */
 int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
-                 float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream);
+                 float* lse, int B, int H, int Nq, int Nk, float scale, int causal,
+                 float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* stream);
 /* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators).
  * dq/dk/dv strides as q/k/v.  Two forms (same results up to bf16 rounding of dq; both deterministic, no float atomics):
  *   two-pass    dQ pass (recomputes S, dP; produces the row constants) then dK/dV pass (recomputes S, dP): 7 MFMA products per tile;
@@ -145,7 +146,13 @@ int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
                  void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
                  void* dv, int64_t dv_bs, int64_t dv_rs,
-                 int B, int H, int Nq, int Nk, float scale, int causal, void* ws, size_t ws_bytes, void* stream);
+                 int B, int H, int Nq, int Nk, float scale, int causal,
+                 float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* ws, size_t ws_bytes, void* stream);
+/* drop_p > 0: attention-probability dropout (transformers BartAttention / SDPA dropout_p = config.attention_dropout, hf:240-252:
+ * softmax, THEN dropout of the probabilities, then P.V).  Element (b, h, q, k) is kept iff a 32-bit hash of its index keyed by
+ * (drop_seed, drop_step, drop_site) clears the 24-bit threshold p; the mask is never stored -- the backward passes re-evaluate it (the
+ * two-pass form only).  crl_attn_dropout_mask writes the same mask as bytes [B, H, Nq, Nk] (tests: the oracle applies the kernels' mask). */
+int crl_attn_dropout_mask(void* keep_u8, int B, int H, int Nq, int Nk, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream);
 
 /* Live per-kernel timing for bench.py's roofline object: between crl_prof_begin and crl_prof_end every launch of an
  * instrumented kernel is bracketed by HIP events on its own stream (pool of `capacity` pairs created up front, no
@@ -284,6 +291,15 @@ int crl_dropout(const void* x, void* y, int64_t n, int is_f32, void* y_bf16, flo
 int crl_dropout_add(const void* x_bf16, const float* resid, float* out, int64_t n, float p, uint64_t seed, uint32_t step,
                     uint32_t site, void* stream);
 int crl_dropout_mask(void* keep_u8, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream);
+/* Drop-path / stochastic depth (timm DropPath on both residual branches of a Swin block; swin_tiny's default drop_path_rate 0.1 is live
+ * in the reference because create_model leaves the encoder in train mode): ONE keep decision per sample and branch.
+ * crl_droppath_scale: scale[b] = keep(b) / (1 - p), keep from Philox(counter b; site, step; seed).
+ * crl_rowscale_add:   out(f32) = resid + float(bf16(x * scale[row / rows_per_sample]))    -- the residual join behind a dropped branch.
+ * crl_rowscale_bf16:  y = bf16(x * scale[row / rows_per_sample])                          -- the gradient entering that branch. */
+int crl_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream);
+int crl_rowscale_add(const void* x_bf16, const float* scale, const float* resid, float* out, int64_t rows, int64_t rows_per_sample, int64_t C,
+                     void* stream);
+int crl_rowscale_bf16(const void* x_bf16, const float* scale, void* y_bf16, int64_t rows, int64_t rows_per_sample, int64_t C, void* stream);
 
 /* ---------------------------------------------------------------- image preprocessing
  * ref: task/task_cruller_pretrain.py:132-143  ToTensor -> Resize(image_size, BICUBIC, antialias=True) -> Normalize.

@@ -88,14 +88,16 @@ def _gelu(x: Tensor) -> Tensor:
 
 
 def _attention(q: Tensor, k: Tensor, v: Tensor, scale: float, causal: bool, policy: str,
-               bias: Optional[Tensor] = None, fast: bool = False) -> Tensor:
+               bias: Optional[Tensor] = None, fast: bool = False, pdrop=None) -> Tensor:
     """softmax(q k^T * scale + bias) v on [B, H, N, d] tensors.
 
     bf16 policy mirrors a flash kernel: scores/softmax in fp32 from bf16 operands, the
     probabilities are rounded to bf16 before P.V, the output is rounded to bf16.
     ``fast`` switches to torch's fused CPU SDPA (used only for timing large shapes).
+    ``pdrop(probabilities [B, H, Nq, Nk])``: attention-probability dropout (hf BartAttention: softmax, dropout, then P.V); the caller
+    supplies the mask (tests: the GPU kernels' own keep mask, crl_attn_dropout_mask).
     """
-    if fast and bias is None:
+    if fast and bias is None and pdrop is None:
         return F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
     qf, kf, vf = q.float(), k.float(), v.float()
     s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
@@ -106,6 +108,8 @@ def _attention(q: Tensor, k: Tensor, v: Tensor, scale: float, causal: bool, poli
         mask = torch.ones(nq, nk, dtype=torch.bool).tril(diagonal=nk - nq)
         s = s.masked_fill(~mask, float('-inf'))
     p = torch.softmax(s, dim=-1)
+    if pdrop is not None:
+        p = pdrop(p)
     if policy == 'bf16':
         p = p.to(BF16).float()
     o = torch.matmul(p, vf)
@@ -227,8 +231,13 @@ def swin_stage_geometry(arch: dict, img_size: Tuple[int, int]):
 
 
 def swin_forward(p: Dict[str, Tensor], arch: dict, image: Tensor, policy: str = 'bf16',
-                 prefix: str = '') -> Tensor:
-    """timm SwinTransformer.forward_features (drop-path off), flattened to [B, H*W/32^2, 8C]."""
+                 prefix: str = '', path=None) -> Tensor:
+    """timm SwinTransformer.forward_features, flattened to [B, H*W/32^2, 8C].  Drop-path (timm DropPath on both residual branches,
+    train mode) is off unless `path(site, branch_output)` is given: site = 2 * global block index + {0: attention, 1: MLP}; the
+    caller supplies the per-sample scales (tests: the GPU's own, crl_droppath_scale)."""
+    if path is None:
+        path = lambda site, t: t
+    gj = 0
     g = lambda n: p[prefix + n]
     eps = arch['ln_eps']
     B = image.shape[0]
@@ -273,10 +282,11 @@ def swin_forward(p: Dict[str, Tensor], arch: dict, image: Tensor, policy: str = 
             o = o.view(B, Hf // w, Wf // w, w, w, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hf, Wf, C)
             if shift:
                 o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-            x = shortcut + o.float()
+            x = shortcut + path(2 * gj, o).float()
             h = _layer_norm(x, g(bp + 'norm2.weight'), g(bp + 'norm2.bias'), eps)
             h = _gelu(_linear(h, g(bp + 'mlp.fc1.weight'), g(bp + 'mlp.fc1.bias'), policy))
-            x = x + _linear(h, g(bp + 'mlp.fc2.weight'), g(bp + 'mlp.fc2.bias'), policy).float()
+            x = x + path(2 * gj + 1, _linear(h, g(bp + 'mlp.fc2.weight'), g(bp + 'mlp.fc2.bias'), policy)).float()
+            gj += 1
     x = _layer_norm(x, g('norm.weight'), g('norm.bias'), eps)
     return x.flatten(1, 2)  # NHWC -> [B, HW, C] (the reference's "# flatten?" TODO)
 
@@ -321,9 +331,14 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
     `drop(site, tensor)` is given: it is applied to the embedding LayerNorm output (site 0) and to the three branch outputs of
     layer i before their residual joins (sites 1 + 3 i + {0: self-attention, 1: cross attention, 2: fc2}) -- the hidden-state
     dropout sites of BartDecoder / BartDecoderLayer; the caller supplies the mask (tests: the GPU kernel's own Philox mask).
+    bart-base additionally drops the FFN activation behind the GELU (`drop.act(300 + i, activation)`, hf:384) and the attention
+    probabilities (`drop.attn(site, probabilities)`, sites 200 + 2 i: self, 201 + 2 i: cross) when the callable carries those attributes.
     """
     if drop is None:
         drop = lambda site, t: t
+    attn_drop = getattr(drop, 'attn', None)
+    act_drop = getattr(drop, 'act', None) or (lambda site, t: t)
+    pd = (lambda site: (lambda pr: attn_drop(site, pr))) if attn_drop is not None else (lambda site: None)
     D, H = arch['d_model'], arch['heads']
     d = D // H
     eps = arch['ln_eps']
@@ -344,7 +359,7 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
         q = _linear(h, g(lp + 'self_attn.q_proj.weight'), g(lp + 'self_attn.q_proj.bias'), policy)
         k = _linear(h, g(lp + 'self_attn.k_proj.weight'), g(lp + 'self_attn.k_proj.bias'), policy)
         v = _linear(h, g(lp + 'self_attn.v_proj.weight'), g(lp + 'self_attn.v_proj.bias'), policy)
-        o = _attention(heads(q, T), heads(k, T), heads(v, T), d ** -0.5, True, policy, fast=fast_attn)
+        o = _attention(heads(q, T), heads(k, T), heads(v, T), d ** -0.5, True, policy, fast=fast_attn, pdrop=pd(200 + 2 * i))
         o = o.transpose(1, 2).reshape(B, T, D)
         o = drop(1 + 3 * i, _linear(o, g(lp + 'self_attn.out_proj.weight'), g(lp + 'self_attn.out_proj.bias'), policy))
         h = _layer_norm(h + o.float(), g(lp + 'self_attn_layer_norm.weight'),
@@ -353,13 +368,13 @@ def bart_decoder_forward(p: Dict[str, Tensor], arch: dict, n_layers: int, input_
         q = _linear(h, g(lp + 'encoder_attn.q_proj.weight'), g(lp + 'encoder_attn.q_proj.bias'), policy)
         k = _linear(enc, g(lp + 'encoder_attn.k_proj.weight'), g(lp + 'encoder_attn.k_proj.bias'), policy)
         v = _linear(enc, g(lp + 'encoder_attn.v_proj.weight'), g(lp + 'encoder_attn.v_proj.bias'), policy)
-        o = _attention(heads(q, T), heads(k, S), heads(v, S), d ** -0.5, False, policy, fast=fast_attn)
+        o = _attention(heads(q, T), heads(k, S), heads(v, S), d ** -0.5, False, policy, fast=fast_attn, pdrop=pd(201 + 2 * i))
         o = o.transpose(1, 2).reshape(B, T, D)
         o = drop(2 + 3 * i, _linear(o, g(lp + 'encoder_attn.out_proj.weight'), g(lp + 'encoder_attn.out_proj.bias'), policy))
         h = _layer_norm(h + o.float(), g(lp + 'encoder_attn_layer_norm.weight'),
                         g(lp + 'encoder_attn_layer_norm.bias'), eps)
         # FFN
-        f = _gelu(_linear(h, g(lp + 'fc1.weight'), g(lp + 'fc1.bias'), policy))
+        f = act_drop(300 + i, _gelu(_linear(h, g(lp + 'fc1.weight'), g(lp + 'fc1.bias'), policy)))
         f = drop(3 + 3 * i, _linear(f, g(lp + 'fc2.weight'), g(lp + 'fc2.bias'), policy))
         h = _layer_norm(h + f.float(), g(lp + 'final_layer_norm.weight'), g(lp + 'final_layer_norm.bias'), eps)
     # tied LM head, no bias
@@ -429,7 +444,7 @@ def cruller_forward(p: Dict[str, Tensor], spec: ModelSpec, image: Tensor, text_i
                     policy: str = 'bf16', fast_attn: bool = False, drop=None) -> Tensor:
     """models/cruller.py:14-21 -> logits [B, T, V]."""
     if spec.enc_kind == 'swin':
-        enc = swin_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.')
+        enc = swin_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.', path=getattr(drop, 'path', None))
     else:
         enc = vit_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.', fast_attn=fast_attn)
     return bart_decoder_forward(p, spec.dec_arch, spec.n_layers, text_input, enc, policy,

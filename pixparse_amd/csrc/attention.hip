@@ -38,7 +38,27 @@ struct AttnArgs {
   float scale;
   int nqt, nkt;
   int fused_delta;     // dQ pass: compute delta = rowsum(dO o O) and -lse/scale itself (and store them for the dK/dV pass that follows)
+  // attention-probability dropout (transformers BartAttention: dropout on the softmax output, p = config.attention_dropout): element
+  // (b, h, q, k) is kept iff hash(((b H + h) Nq + q) Nk + k, drop_key) >> 8 >= drop_thr; kept probabilities are scaled by drop_scale.
+  // The mask is never stored: the forward and both backward passes re-evaluate it (DROP template argument of the kernels).
+  uint32_t drop_thr, drop_key;
+  float drop_scale;
 };
+
+// keep decision of attention dropout: a 32-bit integer hash (multiply / xor-shift rounds, full avalanche) of the element index, keyed by
+// (seed, step, site) through `key`; 24 bits are compared with the threshold
+__host__ __device__ __forceinline__ uint32_t attn_drop_hash(uint32_t x, uint32_t key) {
+  x ^= key;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x >> 8;
+}
+static inline uint32_t attn_drop_key(uint64_t seed, uint32_t step, uint32_t site) {
+  uint32_t k = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ step * 0xC2B2AE3Du ^ site * 0x27D4EB2Fu;
+  k ^= k >> 15; k *= 0x2c1b3c6du; k ^= k >> 12;
+  return k;
+}
 
 // LDS-DMA staging of a 64-row x 64-bf16 tile: per-thread source offset (swizzled chunk of row tid>>3, rows +32 for
 // the second chunk) in a VGPR, everything wave-uniform in the scalar offset.
@@ -78,7 +98,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 #ifndef FWD_ONES
 #define FWD_ONES 0   // 1 = row sums of P on the MFMA pipe (constant ones operand) instead of 32 VALU adds per tile; A/B on one box: 3 % slower
 #endif
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -184,6 +204,15 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
 #if !FWD_ONES
     o2[0] += ps;   // per-lane partial row sum (both lane halves are added at the end)
 #endif
+    if constexpr (DROP) {      // the row sum above is of the UNdropped probabilities (softmax, then dropout); P.V uses the dropped ones
+      const uint32_t xb = ((uint32_t)bh * (uint32_t)a.Nq + (uint32_t)qabs) * (uint32_t)a.Nk + (uint32_t)(k0 + 4 * hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t x = xb + (uint32_t)((r & 3) + 8 * (r >> 2));
+        s0[r] = attn_drop_hash(x, a.drop_key) >= a.drop_thr ? s0[r] * a.drop_scale : 0.f;
+        s1[r] = attn_drop_hash(x + 32u, a.drop_key) >= a.drop_thr ? s1[r] * a.drop_scale : 0.f;
+      }
+    }
     // ---- O^T += V^T . P^T
     __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 
 // ======================================================================================= dK, dV
 // workgroup = 128 keys of one (b,h) (32 per wave, K/V fragments in registers), sweeps query tiles of 64.
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   constexpr int BUF = 2 * 8192 + 512;  // [Q | dO | lse(64 f32) | delta(64 f32)]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -324,7 +353,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
         const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
         const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
         s[4 * g4] = L.x; s[4 * g4 + 1] = L.y; s[4 * g4 + 2] = L.z; s[4 * g4 + 3] = L.w;
-        dp[4 * g4] = Dl.x; dp[4 * g4 + 1] = Dl.y; dp[4 * g4 + 2] = Dl.z; dp[4 * g4 + 3] = Dl.w;
+        if constexpr (DROP) { dp[4 * g4] = 0.f; dp[4 * g4 + 1] = 0.f; dp[4 * g4 + 2] = 0.f; dp[4 * g4 + 3] = 0.f; }   // -delta joins after the mask
+        else { dp[4 * g4] = Dl.x; dp[4 * g4 + 1] = Dl.y; dp[4 * g4 + 2] = Dl.z; dp[4 * g4 + 3] = Dl.w; }
       }
       __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
@@ -340,11 +370,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
         for (int r = 0; r < 16; ++r)
           if (kabs > qbase + acc_row(r, hh) + off) s[r] = -INFINITY;
       }
+      if constexpr (DROP) {
+        // dV takes the dropped probabilities, dP = mask o scale o (dO.V^T), dS = P o (dP - delta)
+        const uint32_t xb = ((uint32_t)bh * (uint32_t)a.Nq + (uint32_t)(qbase + 4 * hh)) * (uint32_t)a.Nk + (uint32_t)kabs;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[r] * c);
-        s[r] = p;
-        dp[r] = p * dp[r];
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] * c);
+          const bool keep = attn_drop_hash(xb + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)a.Nk, a.drop_key) >= a.drop_thr;
+          const float nd = del_s[32 * qb + (r & 3) + 8 * (r >> 2) + 4 * hh];
+          s[r] = keep ? p * a.drop_scale : 0.f;
+          dp[r] = p * ((keep ? dp[r] * a.drop_scale : 0.f) + nd);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] * c);
+          s[r] = p;
+          dp[r] = p * dp[r];
+        }
       }
       __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
 
 // ======================================================================================= dQ
 // workgroup = 128 queries (32 per wave, Q/dO fragments in registers), sweeps key tiles of 64.
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -431,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   }
   f32x16 seedS, seedD;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { seedS[r] = nL; seedD[r] = nD; }
+  for (int r = 0; r < 16; ++r) { seedS[r] = nL; seedD[r] = DROP ? 0.f : nD; }     // with dropout -delta joins after the mask
 
   int kend = a.Nk;
   if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
@@ -469,8 +512,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r)
           if (k0 + 32 * kb + acc_row(r, hh) > lim) s[r] = -INFINITY;   // also keeps exp(-lse) of zero-filled keys out
       }
+      if constexpr (DROP) {
+        const uint32_t xb = ((uint32_t)bh * (uint32_t)a.Nq + (uint32_t)qabs) * (uint32_t)a.Nk + (uint32_t)(k0 + 32 * kb + 4 * hh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
+        for (int r = 0; r < 16; ++r) {
+          const bool keep = attn_drop_hash(xb + (uint32_t)((r & 3) + 8 * (r >> 2)), a.drop_key) >= a.drop_thr;
+          dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * ((keep ? dp[r] * a.drop_scale : 0.f) + nD);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
+      }
       __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -764,6 +816,14 @@ __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const u16* __restri
   *reinterpret_cast<uint4*>(dq + bq * dq_bs + (int64_t)qn * dq_rs + c8 * 8) = o;
 }
 
+int set_drop(const char* who, AttnArgs& a, float p, uint64_t seed, uint32_t step, uint32_t site) {
+  CRL_CHECK(p >= 0.f && p < 1.f, "%s: attention dropout p = %g outside [0, 1)", who, p);
+  a.drop_thr = (uint32_t)(p * 16777216.f + 0.5f);        // 24-bit threshold; 0 = off
+  a.drop_scale = 1.f / (1.f - p);
+  a.drop_key = attn_drop_key(seed, step, site);
+  return 0;
+}
+
 int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) {
   CRL_CHECK(B > 0 && H > 0 && Nq > 0 && Nk > 0, "%s: empty problem", who);
   CRL_CHECK(rs_min >= (int64_t)H * 64, "%s: head_dim is 64 (head h at channel 64 h): a row must hold H * 64 = %d channels, row stride is %lld",
@@ -778,7 +838,8 @@ int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) 
 
 extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                             const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
-                            float* lse, int B, int H, int Nq, int Nk, float scale, int causal, void* stream) {
+                            float* lse, int B, int H, int Nq, int Nk, float scale, int causal,
+                            float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* stream) {
   const char* who = "crl_attn_fwd";
   {
     int64_t rs_min = q_rs;
@@ -793,11 +854,16 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
   a.nqt = (Nq + 127) / 128;
+  if (set_drop(who, a, drop_p, drop_seed, drop_step, drop_site)) return -1;
+  const bool drop = a.drop_thr != 0;
   const unsigned grid = (unsigned)a.nqt * B * H;
   // algorithmic FLOPs: QK^T and PV, 2 x 2 x Nq x Nk x 64 per head (a causal mask halves them when Nq == Nk)
   const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
   CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
-  if (causal) attn_fwd_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
+  if (drop) {
+    if (causal) attn_fwd_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a);
+    else attn_fwd_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a);
+  } else if (causal) attn_fwd_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
   else attn_fwd_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a);
   CRL_PROF_STOP(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream);
   CRL_LAUNCH_CHECK(who);
@@ -832,6 +898,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
                             const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
                             void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
                             void* dv, int64_t dv_bs, int64_t dv_rs, int B, int H, int Nq, int Nk, float scale, int causal,
+                            float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site,
                             void* ws, size_t ws_bytes, void* stream) {
   const char* who = "crl_attn_bwd";
   {
@@ -850,6 +917,8 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   a.do_bs = do_bs; a.do_rs = do_rs; a.dq_bs = dq_bs; a.dq_rs = dq_rs; a.dk_bs = dk_bs; a.dk_rs = dk_rs; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
   a.nqt = (Nq + 127) / 128; a.nkt = (Nk + 127) / 128;
+  if (set_drop(who, a, drop_p, drop_seed, drop_step, drop_site)) return -1;
+  const bool drop = a.drop_thr != 0;
   hipStream_t s = as_stream(stream);
   const int64_t rows = (int64_t)B * H * Nq;
   // normal operation (all parts): the dQ pass runs FIRST and produces the per-query row constants (delta, -lse/scale) as a by-product;
@@ -863,7 +932,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
   }
-  const size_t need = crl_attn_bwd_ws_bytes(B, H, Nq, Nk, causal);
+  const size_t need = drop ? 0 : crl_attn_bwd_ws_bytes(B, H, Nq, Nk, causal);     // the single-pass form has no dropout variant
   if (need && ws && ws_bytes >= need) {
     // ---- fused single pass: row constants, then dK / dV / partial dQ slabs from one recomputation, then the slab reduce
     CRL_CHECK(((uintptr_t)ws % 16) == 0 && (dq_rs % 8) == 0, "%s: workspace / dq must be 16-byte aligned", who);
@@ -898,7 +967,8 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   auto run_dkdv = [&]() -> int {
     if (g_bwd_parts & 2) {
       CRL_PROF_START(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream, 6.0 * 64 * pairs * B * H);
-      if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
+      if (drop) { if (causal) attn_bwd_dkdv_kernel<true, true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false, true><<<gk, 256, 0, s>>>(a); }
+      else if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
       CRL_PROF_STOP(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream);
     }
     CRL_LAUNCH_CHECK("crl_attn_bwd(dkdv)");
@@ -907,7 +977,8 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   auto run_dq = [&]() -> int {
     if (g_bwd_parts & 4) {
       CRL_PROF_START(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream, 2.0 * 64 * pairs * B * H);
-      if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
+      if (drop) { if (causal) attn_bwd_dq_kernel<true, true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false, true><<<gq, 256, 0, s>>>(a); }
+      else if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
       CRL_PROF_STOP(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream);
     }
     CRL_LAUNCH_CHECK("crl_attn_bwd(dq)");
@@ -915,5 +986,20 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   };
   if (fused) { if (int rc = run_dq()) return rc; if (int rc = run_dkdv()) return rc; }
   else { if (int rc = run_dkdv()) return rc; if (int rc = run_dq()) return rc; }
+  return 0;
+}
+
+// keep mask of the attention dropout as bytes [B, H, Nq, Nk] (1 = kept): lets the CPU oracle apply the very mask the kernels regenerate
+namespace {
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* __restrict__ keep, uint64_t n, uint32_t thr, uint32_t key) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = attn_drop_hash((uint32_t)i, key) >= thr ? 1 : 0;
+}
+}  // namespace
+extern "C" int crl_attn_dropout_mask(void* keep_u8, int B, int H, int Nq, int Nk, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream) {
+  CRL_CHECK(keep_u8 && B > 0 && H > 0 && Nq > 0 && Nk > 0 && p >= 0.f && p < 1.f, "crl_attn_dropout_mask: bad arguments");
+  const uint64_t n = (uint64_t)B * H * Nq * Nk;
+  attn_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>((uint8_t*)keep_u8, n, (uint32_t)(p * 16777216.f + 0.5f), attn_drop_key(seed, step, site));
+  CRL_LAUNCH_CHECK("crl_attn_dropout_mask");
   return 0;
 }

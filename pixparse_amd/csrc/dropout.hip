@@ -94,6 +94,47 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
   *reinterpret_cast<uint2*>(keep + g * 8) = uint2{lo, hi};
 }
 
+// ---- drop-path (stochastic depth, timm DropPath on the two residual branches of a Swin block): ONE keep decision per sample
+// scale[b] = keep(b) / (1 - p): the first 16-bit uniform of Philox(counter b; site, step; seed)
+__global__ void droppath_scale_kernel(float* __restrict__ scale, int B, DropArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const U4 r = philox4x32_10((uint32_t)b, 0u, a.site, a.step, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  scale[b] = (r.x & 0xffffu) >= a.thr ? a.scale : 0.f;
+}
+// out(f32) = resid + float(bf16(x * scale[row / rows_per_sample]))      (8 elements per thread; C % 8 == 0)
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const u16* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ resid,
+                                                           float* __restrict__ out, uint64_t ngroups, uint64_t groups_per_sample) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const float sc = scale[g / groups_per_sample];
+  const uint4 v = *reinterpret_cast<const uint4*>(x + g * 8);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const float4 r0 = *reinterpret_cast<const float4*>(resid + g * 8), r1 = *reinterpret_cast<const float4*>(resid + g * 8 + 4);
+  const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = r[2 * j] + round_bf(bf2f(w[j] & 0xffff) * sc);
+    f[2 * j + 1] = r[2 * j + 1] + round_bf(bf2f(w[j] >> 16) * sc);
+  }
+  *reinterpret_cast<float4*>(out + g * 8) = float4{f[0], f[1], f[2], f[3]};
+  *reinterpret_cast<float4*>(out + g * 8 + 4) = float4{f[4], f[5], f[6], f[7]};
+}
+// y(bf16) = bf16(x * scale[row / rows_per_sample])      (the gradient entering a dropped branch)
+__global__ __launch_bounds__(256) void rowscale_bf16_kernel(const u16* __restrict__ x, const float* __restrict__ scale, u16* __restrict__ y, uint64_t ngroups,
+                                                            uint64_t groups_per_sample) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const float sc = scale[g / groups_per_sample];
+  const uint4 v = *reinterpret_cast<const uint4*>(x + g * 8);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf2f(w[j] & 0xffff) * sc, bf2f(w[j] >> 16) * sc);
+  *reinterpret_cast<uint4*>(y + g * 8) = uint4{o[0], o[1], o[2], o[3]};
+}
+
 int drop_args(const char* who, int64_t n, float p, uint64_t seed, uint32_t step, uint32_t site, DropArgs& a) {
   CRL_CHECK(n > 0 && (n % 8) == 0, "%s: element count %lld must be a positive multiple of 8", who, (long long)n);
   CRL_CHECK(p >= 0.f && p < 1.f, "%s: p = %g outside [0, 1)", who, p);
@@ -133,5 +174,33 @@ extern "C" int crl_dropout_mask(void* keep_u8, int64_t n, float p, uint64_t seed
   CRL_CHECK(keep_u8 && ((uintptr_t)keep_u8 % 8) == 0, "crl_dropout_mask: null / unaligned pointer");
   dropout_mask_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>((uint8_t*)keep_u8, (uint64_t)n / 8, a);
   CRL_LAUNCH_CHECK("crl_dropout_mask");
+  return 0;
+}
+
+extern "C" int crl_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t step, uint32_t site, void* stream) {
+  DropArgs a;
+  if (drop_args("crl_droppath_scale", 8, p, seed, step, site, a)) return -1;
+  CRL_CHECK(scale && B > 0, "crl_droppath_scale: bad arguments");
+  droppath_scale_kernel<<<(unsigned)((B + 63) / 64), 64, 0, as_stream(stream)>>>(scale, B, a);
+  CRL_LAUNCH_CHECK("crl_droppath_scale");
+  return 0;
+}
+
+extern "C" int crl_rowscale_add(const void* x_bf16, const float* scale, const float* resid, float* out, int64_t rows, int64_t rows_per_sample, int64_t C,
+                                void* stream) {
+  CRL_CHECK(x_bf16 && scale && resid && out && rows > 0 && rows_per_sample > 0 && C > 0 && (C % 8) == 0 && (rows % rows_per_sample) == 0,
+            "crl_rowscale_add: bad arguments (C must be a multiple of 8, rows a multiple of rows_per_sample)");
+  const int64_t n = rows * C;
+  rowscale_add_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>((const u16*)x_bf16, scale, resid, out, (uint64_t)n / 8, (uint64_t)(rows_per_sample * C / 8));
+  CRL_LAUNCH_CHECK("crl_rowscale_add");
+  return 0;
+}
+
+extern "C" int crl_rowscale_bf16(const void* x_bf16, const float* scale, void* y_bf16, int64_t rows, int64_t rows_per_sample, int64_t C, void* stream) {
+  CRL_CHECK(x_bf16 && scale && y_bf16 && rows > 0 && rows_per_sample > 0 && C > 0 && (C % 8) == 0 && (rows % rows_per_sample) == 0,
+            "crl_rowscale_bf16: bad arguments (C must be a multiple of 8, rows a multiple of rows_per_sample)");
+  const int64_t n = rows * C;
+  rowscale_bf16_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>((const u16*)x_bf16, scale, (u16*)y_bf16, (uint64_t)n / 8, (uint64_t)(rows_per_sample * C / 8));
+  CRL_LAUNCH_CHECK("crl_rowscale_bf16");
   return 0;
 }

@@ -35,9 +35,10 @@ SIGNATURES = {
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),
     'crl_layernorm_bwd_ws_bytes': (Z, [L]),
     'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, P, I, P, P]),
-    'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, P]),
+    'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, F, U64, U32, U32, P]),
+    'crl_attn_dropout_mask': (I, [P, I, I, I, I, F, U64, U32, U32, P]),
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
-                         I, I, I, I, F, I, P, Z, P]),
+                         I, I, I, I, F, I, F, U64, U32, U32, P, Z, P]),
     'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
     'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),
@@ -67,6 +68,9 @@ SIGNATURES = {
     'crl_dropout': (I, [P, P, L, I, P, F, U64, U32, U32, P]),
     'crl_dropout_add': (I, [P, P, P, L, F, U64, U32, U32, P]),
     'crl_dropout_mask': (I, [P, L, F, U64, U32, U32, P]),
+    'crl_droppath_scale': (I, [P, I, F, U64, U32, U32, P]),
+    'crl_rowscale_add': (I, [P, P, P, P, L, L, L, P]),
+    'crl_rowscale_bf16': (I, [P, P, P, L, L, L, P]),
     'crl_image_preprocess_u8': (I, [P, I, I, I, P, P, P, I, P, P, P, I, P, P, P, P, I, I, P]),
 }
 

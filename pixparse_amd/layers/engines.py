@@ -242,6 +242,35 @@ class SwinEngine(_Base):
         self.Kreal = in_chans * self.P_ * self.P_
         self.Kp = ops.round_up(self.Kreal, ops.K_PAD)
         self.pe_shadow = None
+        # drop-path (timm DropPath on both residual branches; rate of block j of n = drop.p_path * j / (n - 1)) of the NEXT forward /
+        # backward pair: an ops.DropSpec with p_path > 0, or None.  Sites 2 j (attention branch) and 2 j + 1 (MLP branch).
+        self.drop: Optional[ops.DropSpec] = None
+        self.nblocks = sum(arch['depths'])
+
+    def _path_rate(self, j: int) -> float:
+        if self.drop is None or not self.drop.p_path or self.nblocks < 2:
+            return 0.0
+        return self.drop.p_path * j / (self.nblocks - 1)
+
+    def _join(self, x, w, b, out, resid, key, j, branch, rows):
+        """out(f32) = resid + [drop_path](bf16(x @ w^T + b)); the per-sample scales stay in `key` for the backward pass"""
+        rate = self._path_rate(j)
+        if rate <= 0.0:
+            ops.linear_fwd(x, w, b, out, EPI_F32_RESID, resid=resid)
+            return
+        tmp = self.buf('dp.tmp', (x.shape[0], w.shape[0]), BF16)
+        ops.linear_fwd(x, w, b, tmp)
+        scale = self.buf(key, (self.B,), F32)
+        ops.droppath_scale(scale, rate, self.drop, 2 * j + branch)
+        ops.rowscale_add(tmp, scale, resid, out, rows)
+
+    def _branch_grad(self, gb, key, j, rows, name):
+        """gradient entering a (possibly dropped) branch: gb itself, or bf16(gb * scale[sample]) in a scratch buffer"""
+        if self._path_rate(j) <= 0.0:
+            return gb
+        out = self.buf(name, gb.shape, BF16)
+        ops.rowscale_bf16(gb, self.bufs.t[self.tag + '.' + key], out, rows)
+        return out
 
     @staticmethod
     def stage_geometry(arch, img_size):
@@ -303,6 +332,7 @@ class SwinEngine(_Base):
         pe32 = self.buf('pe32', (B * Hf0 * Wf0, C0), F32)
         ops.add_bf16_to_f32(pe, pe32, False)
         x, _ = self.ln_fwd('patch_embed.norm', pe32, 'pe_norm', eps, want_f32=True, want_bf16=False)
+        gj = 0          # global block index (drop-path schedule)
         for si, (Hf, Wf, C, heads, w, depth) in enumerate(self.geo):
             sp, M = f'layers.{si}.', B * Hf * Wf
             if si > 0:
@@ -325,15 +355,16 @@ class SwinEngine(_Base):
                 o = self.buf(k + '.o', (M, C), BF16)
                 ops.swin_attn_fwd(qkv, self.P(bp + 'attn.relative_position_bias_table'), o, B, Hf, Wf, heads, w, shift, scale)
                 x2 = self.buf(k + '.x2', (M, C), F32)
-                ops.linear_fwd(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, EPI_F32_RESID, resid=x)
+                self._join(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, x, k + '.dps1', gj, 0, Hf * Wf)
                 _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
                 pre = self.buf(k + '.pre', (M, F_), BF16)
                 act = self.buf(k + '.act', (M, F_), BF16)
                 ops.linear_fwd(h2, self.W(bp + 'mlp.fc1.weight'), self.P(bp + 'mlp.fc1.bias'), act, EPI_BF16_GELU, aux=pre)
                 x3 = self.buf(k + '.x3', (M, C), F32)
-                ops.linear_fwd(act, self.W(bp + 'mlp.fc2.weight'), self.P(bp + 'mlp.fc2.bias'), x3, EPI_F32_RESID, resid=x2)
+                self._join(act, self.W(bp + 'mlp.fc2.weight'), self.P(bp + 'mlp.fc2.bias'), x3, x2, k + '.dps2', gj, 1, Hf * Wf)
                 self.bufs.t[self.tag + '.' + k + '.xin'] = x
                 x = x3
+                gj += 1
         self.x_last = x
         return self.ln_fwd('norm', x, 'norm', eps, want_f32=True, want_bf16=True)
 
@@ -345,8 +376,10 @@ class SwinEngine(_Base):
         self.ln_bwd('norm', 'norm', self.x_last, denc, None, dx, False, gb)
         if on_layer_done:
             on_layer_done(self.prefix + 'norm.weight')
+        gj_end = self.nblocks
         for si in reversed(range(len(self.geo))):
             Hf, Wf, C, heads, w, depth = self.geo[si]
+            gj_end -= depth          # global index of this stage's first block
             sp, M = f'layers.{si}.', B * Hf * Wf
             F_ = C * a['mlp_ratio']
             scale = (C // heads) ** -0.5
@@ -360,13 +393,16 @@ class SwinEngine(_Base):
                 xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
                 h1, h2 = T[tg + k + '.ln1.y16'], T[tg + k + '.ln2.y16']
                 qkv, o, pre, act = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.pre'], T[tg + k + '.act']
-                ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
-                self.lin_wgrad(bp + 'mlp.fc2', gb, act)
+                gj = gj_end + bi
+                gm = self._branch_grad(gb, k + '.dps2', gj, Hf * Wf, f'gbs{si}')      # d(MLP branch output) = drop-path scale o d(x3)
+                ops.linear_dgrad(gm, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
+                self.lin_wgrad(bp + 'mlp.fc2', gm, act)
                 ops.linear_dgrad(dpre, self.W(bp + 'mlp.fc1.weight'), dh)
                 self.lin_wgrad(bp + 'mlp.fc1', dpre, h2)
                 self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb)
-                ops.linear_dgrad(gb, self.W(bp + 'attn.proj.weight'), do)
-                self.lin_wgrad(bp + 'attn.proj', gb, o)
+                ga = self._branch_grad(gb, k + '.dps1', gj, Hf * Wf, f'gbs{si}')      # d(attention branch output)
+                ops.linear_dgrad(ga, self.W(bp + 'attn.proj.weight'), do)
+                self.lin_wgrad(bp + 'attn.proj', ga, o)
                 ops.swin_attn_bwd(qkv, self.P(bp + 'attn.relative_position_bias_table'), do, dqkv,
                                   self.G(bp + 'attn.relative_position_bias_table'), B, Hf, Wf, heads, w, shift, scale)
                 ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
@@ -415,9 +451,12 @@ class BartEngine(_Base):
         # cross-attention / fc2 branch of layer i before its residual join (modeling_bart.py:362,377,384-386,654).
         self.drop: Optional[ops.DropSpec] = None
 
+    def _hidden_drop(self):
+        return self.drop is not None and self.drop.p > 0
+
     def _branch(self, x, w, b, out, resid, site):
         """out(f32) = resid + [dropout](bf16(x @ w^T + b)): the residual join behind an attention / FFN branch"""
-        if self.drop is None:
+        if not self._hidden_drop():
             ops.linear_fwd(x, w, b, out, EPI_F32_RESID, resid=resid)
         else:
             tmp = self.buf('drop.tmp', (x.shape[0], w.shape[0]), BF16)
@@ -427,7 +466,7 @@ class BartEngine(_Base):
     def _branch_bwd(self, ln_name, key, x, dy32, dyb, dx32, dxb, bias_of, site):
         """LayerNorm backward behind a residual join; dxb = the (dropped) gradient of the branch's Linear output, whose bias
         gradient is its column sum (fused into the LayerNorm backward when there is no mask to apply first)"""
-        if self.drop is None:
+        if not self._hidden_drop():
             self.ln_bwd(ln_name, key, x, dy32, dyb, dx32, False, dxb, bias_of=bias_of)
         else:
             self.ln_bwd(ln_name, key, x, dy32, dyb, dx32, False, dxb)
@@ -480,8 +519,11 @@ class BartEngine(_Base):
         emb = self.buf('emb', (M, D), F32)
         ops.embed_fwd(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, 2)
         h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'ln_emb', eps, want_f32=True, want_bf16=True)
-        if self.drop is not None:
+        if self._hidden_drop():
             ops.dropout(h, h, self.drop, 0, y_bf16=hb)
+        # attention-probability dropout (sites 200 + 2 i: self, 201 + 2 i: cross; hf BartAttention dropout = config.attention_dropout) and
+        # activation dropout behind the GELU (site 300 + i; hf:384): live only when the DropSpec carries p_attn / p_act (bart-base)
+        drop, p_act = self.drop, (self.drop.p_act if self.drop is not None else 0.0)
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
@@ -489,7 +531,7 @@ class BartEngine(_Base):
             q3 = qkv.view(B, T, 3 * D)
             o1 = self.buf(k + '.o1', (M, D), BF16)
             lse1 = self.buf(k + '.lse1', (B, H, T), F32)
-            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True)
+            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True, drop=drop, site=200 + 2 * i)
             t1 = self.buf(k + '.t1', (M, D), F32)
             self._branch(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, h, 1 + 3 * i)
             h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
@@ -500,13 +542,15 @@ class BartEngine(_Base):
             kv3 = kv2.view(B, S, 2 * D)
             o2 = self.buf(k + '.o2', (M, D), BF16)
             lse2 = self.buf(k + '.lse2', (B, H, T), F32)
-            ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False)
+            ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False, drop=drop, site=201 + 2 * i)
             t2 = self.buf(k + '.t2', (M, D), F32)
             self._branch(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, h1, 2 + 3 * i)
             h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
             pre = self.buf(k + '.pre', (M, F_), BF16)
             act = self.buf(k + '.act', (M, F_), BF16)
             ops.linear_fwd(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU, aux=pre)
+            if p_act:
+                ops.dropout(act, act, drop, 300 + i, p=p_act)      # the saved activation IS the dropped one (what fc2 and its wgrad read)
             t3 = self.buf(k + '.t3', (M, D), F32)
             self._branch(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, h2, 3 + 3 * i)
             self.bufs.t[self.tag + '.' + k + '.hb'] = hb
@@ -658,12 +702,15 @@ class BartEngine(_Base):
         delta = self.buf('delta', (2, B, H, T), F32)
         if self.L == 0:
             denc.zero_()
+        drop, p_act = self.drop, (self.drop.p_act if self.drop is not None else 0.0)
         for i in reversed(range(self.L)):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             g = lambda n: Tb[tg + k + n]
             # ---- h_out = LN3(t3), t3 = h2 + fc2(gelu(fc1(h2b)))
             self._branch_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, dtb, lp + 'fc2', 3 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.pre'))
+            if p_act:
+                ops.dropout(dpre, dpre, drop, 300 + i, p=p_act)    # mask o scale and gelu' are both elementwise: applied behind the fused dGELU epilogue
             self.lin_wgrad(lp + 'fc2', dtb, g('.act'), has_bias=False)
             ops.linear_dgrad(dpre, self.W(lp + 'fc1.weight'), dhb)
             self.lin_wgrad(lp + 'fc1', dpre, g('.ln2.y16'))
@@ -673,7 +720,7 @@ class BartEngine(_Base):
             self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'), has_bias=False)
             kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
             ops.attn_bwd(g('.q2').view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], g('.o2').view(B, T, D), do.view(B, T, D), g('.lse2'), delta,
-                         dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False)
+                         dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False, drop=drop, site=201 + 2 * i)
             ops.linear_dgrad(dq2, self.W(lp + 'encoder_attn.q_proj.weight'), dhb)
             self.lin_wgrad(lp + 'encoder_attn.q_proj', dq2, g('.ln1.y16'))
             # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
@@ -686,7 +733,7 @@ class BartEngine(_Base):
             self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'), has_bias=False)
             q3, dq3 = g('.qkv').view(B, T, 3 * D), dqkv.view(B, T, 3 * D)
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
-                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True)
+                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True, drop=drop, site=200 + 2 * i)
             ops.linear_dgrad(dqkv, self.fw('w', lp, 'self_attn', 'q_proj', 3), dyb)
             ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True)
             ops.colsum(dqkv, self.fb('g', lp, 'self_attn', 'q_proj', 3), True)
@@ -695,7 +742,7 @@ class BartEngine(_Base):
                 on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')
         # ---- h0 = LN(emb)
         demb = self.buf('demb', (M, D), F32)
-        if self.drop is not None:      # the mask of site 0 on both gradient streams arriving at the embedding LayerNorm output
+        if self._hidden_drop():        # the mask of site 0 on both gradient streams arriving at the embedding LayerNorm output
             ops.dropout(dy32, dy32, self.drop, 0)
             ops.dropout(dyb, dyb, self.drop, 0)
         self.ln_bwd(dp + 'layernorm_embedding', 'ln_emb', Tb[tg + 'emb'], dy32, dyb, demb, False, None)

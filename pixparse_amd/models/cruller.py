@@ -249,17 +249,22 @@ class Cruller(nn.Module):
         """Opt-in hidden-state dropout of the text decoder inside forward_loss() / backward(): the reference's
         decoder runs it only when built with pretrained=False (BartForCausalLM from_config stays in train mode, p = config.dropout;
         text_decoder_hf.py:25-33); parity runs, bench.py and every eval / generation path keep it off.  The mask of micro-step s is
-        a pure function of (seed, s, site, element) -- crl_dropout in include/crl.h."""
+        a pure function of (seed, s, site, element) -- crl_dropout in include/crl.h.  Covers all four train-mode regularisers of the
+        reference's models: hidden-state dropout, attention-probability and activation dropout (bart-base) and the Swin encoder's
+        drop-path (timm's default drop_path_rate 0.1; create_model leaves the encoder in train mode)."""
         p = float(self.dec_arch.get('dropout', 0.0))
-        if enabled and (self.dec_arch.get('attention_dropout', 0.0) or self.dec_arch.get('activation_dropout', 0.0)):
-            raise NotImplementedError(f'{self.cfg.text_decoder.name}: attention / activation dropout are not implemented (hidden-state dropout only)')
-        self._drop = (p, int(seed)) if enabled and p > 0 else None
+        p_attn = float(self.dec_arch.get('attention_dropout', 0.0))       # bart-base: dropout of the attention probabilities (hf BartAttention)
+        p_act = float(self.dec_arch.get('activation_dropout', 0.0))       # bart-base: dropout behind the FFN's GELU (hf:384)
+        p_path = float(self.enc_arch.get('drop_path', 0.0)) if self.enc_kind == 'swin' else 0.0   # timm Swin drop-path (train-mode encoder)
+        self._drop = (p, int(seed), p_attn, p_act, p_path) if enabled and max(p, p_attn, p_act, p_path) > 0 else None
         self._drop_step = 0
 
     def forward(self, image_input: torch.Tensor, text_input: torch.Tensor, _drop=None):
         """ref models/cruller.py:14-21 -> output['logits'] bf16 [B, T, V] (a view of the padded logits buffer)."""
         enc, dec, _ = self._ensure_engines()
         dec.drop = _drop
+        if self.enc_kind == 'swin':
+            enc.drop = _drop          # drop-path of the encoder's residual branches (None outside forward_loss / backward pairs)
         enc32, enc16 = self.encode(image_input)
         B, T = text_input.shape
         logits = dec.forward(text_input.contiguous(), enc16, enc.out_tokens())
@@ -270,6 +275,8 @@ class Cruller(nn.Module):
     def encode_image(self, image_input: torch.Tensor) -> torch.Tensor:
         """what the reference's eval tasks call `model.image_encoder(image)`: last hidden states fp32 [B, S, D]"""
         enc, _, _ = self._ensure_engines()
+        if self.enc_kind == 'swin':
+            enc.drop = None           # eval path: never the drop-path masks of an earlier training step
         enc32, _ = self.encode(image_input)
         return enc32.view(image_input.shape[0], enc.out_tokens(), -1)
 
@@ -372,7 +379,7 @@ class Cruller(nn.Module):
         enc, dec, bufs = self._ensure_engines()
         drop = None
         if getattr(self, '_drop', None) is not None:
-            drop = ops.DropSpec(self._drop[0], self._drop[1], self._drop_step)
+            drop = ops.DropSpec(self._drop[0], self._drop[1], self._drop_step, *self._drop[2:])
             self._drop_step += 1
         self.forward(image_input, text_input, _drop=drop)   # dec.drop stays set for the matching backward()
         B, T = text_input.shape
@@ -395,6 +402,8 @@ class Cruller(nn.Module):
         dec.backward(bufs.t['dec.logits'], bufs.t[enc.tag + '.norm.y16'], denc, on_ready)
         enc.backward(denc, on_ready)
         dec.drop = None       # the mask belongs to this forward_loss() / backward() pair only
+        if self.enc_kind == 'swin':
+            enc.drop = None
 
     def activation_bytes(self) -> int:
         return 0 if self._engines is None else self._engines[2].bytes()

@@ -141,13 +141,29 @@ def _bs_rs(t: torch.Tensor):
     return t.stride(0), t.stride(1)
 
 
-def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool) -> None:
-    """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32."""
+def _drop_args(drop, site):
+    """(p, seed, step, site) of an attention-probability dropout call; drop: DropSpec-like with .p_attn (None / 0 = off)"""
+    if drop is None or not getattr(drop, 'p_attn', 0.0):
+        return 0.0, 0, 0, 0
+    return float(drop.p_attn), drop.seed, drop.step, int(site)
+
+
+def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool, drop=None, site: int = 0) -> None:
+    """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32.
+    drop (DropSpec with p_attn > 0) + site: dropout of the attention probabilities (the backward call must pass the same pair)."""
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o)
     hip.call('crl_attn_fwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o), _p(lse),
-             B, heads, Nq, Nk, float(scale), int(causal), _stream())
+             B, heads, Nq, Nk, float(scale), int(causal), *_drop_args(drop, site), _stream())
+
+
+def attn_dropout_mask(B: int, H: int, Nq: int, Nk: int, drop, site: int, device) -> torch.Tensor:
+    """the keep mask [B, H, Nq, Nk] (uint8) the attention kernels regenerate for (drop, site)"""
+    keep = torch.empty(B, H, Nq, Nk, dtype=torch.uint8, device=device)
+    p, seed, step, st = _drop_args(drop, site)
+    hip.call('crl_attn_dropout_mask', _p(keep), B, H, Nq, Nk, p, seed, step, st, _stream())
+    return keep
 
 
 def attn_decode(q, k, v, o, heads: int, scale: float, nk_minus1: Optional[torch.Tensor] = None,
@@ -171,7 +187,7 @@ def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) ->
              _stream())
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool) -> None:
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool, drop=None, site: int = 0) -> None:
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)
@@ -179,7 +195,7 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, 
     ws = _attn_scratch.get(wsb, q.device) if wsb else None
     hip.call('crl_attn_bwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o),
              _p(d_o), *_bs_rs(d_o), _p(lse), _p(delta), _p(dq), *_bs_rs(dq), _p(dk), *_bs_rs(dk), _p(dv), *_bs_rs(dv),
-             B, heads, Nq, Nk, float(scale), int(causal), _p(ws), wsb, _stream())
+             B, heads, Nq, Nk, float(scale), int(causal), *_drop_args(drop, site), _p(ws), wsb, _stream())
 
 
 def swin_attn_fwd(qkv, table, out, B, Hf, Wf, heads, w, shift, scale) -> None:
@@ -273,14 +289,36 @@ def cast_pad_bf16(src, dst, R: int, C: int, Cp: int) -> None:
 class DropSpec:
     """(p, seed, step) of one forward / backward pair; site ids are chosen by the caller (one per dropout call site)"""
 
-    def __init__(self, p: float, seed: int, step: int):
+    def __init__(self, p: float, seed: int, step: int, p_attn: float = 0.0, p_act: float = 0.0, p_path: float = 0.0):
+        """p: hidden-state dropout; p_attn: attention-probability dropout; p_act: activation (post-GELU) dropout; p_path: the
+        encoder's maximum drop-path rate (Swin: per block linearly from 0 to p_path)"""
         self.p, self.seed, self.step = float(p), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 32 - 1)
+        self.p_attn, self.p_act, self.p_path = float(p_attn), float(p_act), float(p_path)
 
 
-def dropout(x: torch.Tensor, y: torch.Tensor, d: DropSpec, site: int, y_bf16: Optional[torch.Tensor] = None) -> None:
-    """y = dropout(x) (bf16 or fp32, in place allowed); fp32 inputs may emit a bf16 copy of the result"""
+def dropout(x: torch.Tensor, y: torch.Tensor, d: DropSpec, site: int, y_bf16: Optional[torch.Tensor] = None, p: Optional[float] = None) -> None:
+    """y = dropout(x) (bf16 or fp32, in place allowed); fp32 inputs may emit a bf16 copy of the result. p overrides d.p (activation dropout)"""
     assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
-    hip.call('crl_dropout', _p(x), _p(y), x.numel(), int(x.dtype == F32), _p(y_bf16), d.p, d.seed, d.step, site, _stream())
+    hip.call('crl_dropout', _p(x), _p(y), x.numel(), int(x.dtype == F32), _p(y_bf16), d.p if p is None else float(p), d.seed, d.step, site, _stream())
+
+
+def droppath_scale(scale: torch.Tensor, p: float, d: DropSpec, site: int) -> None:
+    """scale[b] = keep(b) / (1 - p): one drop-path decision per sample for (d.seed, d.step, site)"""
+    _chk(scale, F32, 'droppath scale')
+    hip.call('crl_droppath_scale', _p(scale), scale.numel(), float(p), d.seed, d.step, site, _stream())
+
+
+def rowscale_add(x_bf16: torch.Tensor, scale: torch.Tensor, resid: torch.Tensor, out: torch.Tensor, rows_per_sample: int) -> None:
+    """out(f32) = resid + bf16(x * scale[sample of the row])"""
+    M, C = x_bf16.shape
+    assert x_bf16.is_contiguous() and resid.is_contiguous() and out.is_contiguous()
+    hip.call('crl_rowscale_add', _p(x_bf16), _p(scale), _p(resid), _p(out), M, int(rows_per_sample), C, _stream())
+
+
+def rowscale_bf16(x_bf16: torch.Tensor, scale: torch.Tensor, y_bf16: torch.Tensor, rows_per_sample: int) -> None:
+    M, C = x_bf16.shape
+    assert x_bf16.is_contiguous() and y_bf16.is_contiguous()
+    hip.call('crl_rowscale_bf16', _p(x_bf16), _p(scale), _p(y_bf16), M, int(rows_per_sample), C, _stream())
 
 
 def dropout_add(x_bf16: torch.Tensor, resid: torch.Tensor, out: torch.Tensor, d: DropSpec, site: int) -> None:
@@ -291,9 +329,9 @@ def dropout_add(x_bf16: torch.Tensor, resid: torch.Tensor, out: torch.Tensor, d:
     hip.call('crl_dropout_add', _p(x_bf16), _p(resid), _p(out), x_bf16.numel(), d.p, d.seed, d.step, site, _stream())
 
 
-def dropout_mask(n: int, d: DropSpec, site: int, device) -> torch.Tensor:
+def dropout_mask(n: int, d: DropSpec, site: int, device, p: Optional[float] = None) -> torch.Tensor:
     keep = torch.empty(n, dtype=torch.uint8, device=device)
-    hip.call('crl_dropout_mask', _p(keep), n, d.p, d.seed, d.step, site, _stream())
+    hip.call('crl_dropout_mask', _p(keep), n, d.p if p is None else float(p), d.seed, d.step, site, _stream())
     return keep
 
 

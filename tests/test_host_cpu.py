@@ -77,7 +77,7 @@ def test_argument_validation_without_gpu():
     with pytest.raises(hip.HipLibraryError, match='multiple of 32'):
         hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, None, 0, None)
     with pytest.raises(hip.HipLibraryError, match='empty'):
-        hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, None)
+        hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, 0.0, 0, 0, 0, None)
     with pytest.raises(hip.HipLibraryError, match='window'):
         hip.call('crl_swin_attn_fwd', 16, 16, 16, 1, 18, 18, 1, 9, 0, 0.1, None)
 
@@ -162,16 +162,20 @@ def test_no_cpu_fallback():
 
 
 def test_decoder_dropout_switch_cpu():
-    """dropout is an explicit opt-in (task cfg `decoder_dropout`, Cruller.set_train_dropout); decoders whose config also
-    drops attention probabilities / activations (bart-base) are refused rather than trained with a silently different regulariser"""
+    """dropout is an explicit opt-in (task cfg `decoder_dropout`, Cruller.set_train_dropout).  With it on, a model gets
+    every train-mode regulariser of its reference counterpart: hidden-state dropout, bart-base's attention-probability and activation
+    dropout, and the Swin encoder's drop-path (timm default 0.1)"""
     from pixparse_amd.models import Cruller, get_model_config
     from pixparse_amd.task import TaskCrullerPretrainCfg
     assert TaskCrullerPretrainCfg().decoder_dropout is False
     small = Cruller(get_model_config('cruller_small'), vocab_size=515)        # swin_tiny + bart-base
-    with pytest.raises(NotImplementedError, match='attention / activation dropout'):
-        small.set_train_dropout(True)
+    small.set_train_dropout(True, seed=7)
+    assert small._drop == (0.1, 7, 0.1, 0.1, 0.1)                              # (hidden, seed, attention, activation, drop-path)
     small.set_train_dropout(False)
     assert small._drop is None
+    large = Cruller(get_model_config('cruller_base'), vocab_size=515)         # ViT (no drop-path) + bart-base
+    large.set_train_dropout(True)
+    assert large._drop == (0.1, 0, 0.1, 0.1, 0.0)
 
 
 def test_task_surface_and_counters_cpu():

@@ -197,6 +197,91 @@ def test_decoder_dropout_matches_oracle_with_the_same_masks(dev):
     assert out.logits.shape == (B, T, V)
 
 
+def test_attention_activation_dropout_and_drop_path_match_oracle(dev):
+    """SURVEY K20 completion: the train-mode regularisers of cfg-1's reference models -- bart-base's attention-probability dropout (inside
+    the flash kernels: softmax, mask, P.V; the backward passes regenerate the mask) and activation dropout behind the GELU, and the Swin
+    encoder's drop-path on both residual branches (per-sample scales, linearly increasing rate) -- next to the hidden-state dropout.
+    The oracle applies, at the reference's sites, the very masks / scales the HIP kernels generate (crl_attn_dropout_mask,
+    crl_dropout_mask, crl_droppath_scale): loss and every gradient agree to the tolerances of the dropout-free test; switching it off
+    restores the dropout-free loss bit for bit; forward() alone never drops."""
+    from oracle import ref_cpu as R
+    from pixparse_amd import ops
+    from pixparse_amd.models import Cruller
+    _register_test_archs()
+    enc, img, fmt = 'swin_test', (64, 64), 'RGB'
+    L, layers, V, B = 24, 2, 515, 2
+    torch.manual_seed(1)
+    model = Cruller(_cfg(enc, img, fmt, layers, L), vocab_size=V)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.bias'):
+                p.normal_(0, 0.05)
+            elif p.dim() >= 2:
+                p.mul_(3.0)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith('lm_head.weight')}
+    spec = R.ModelSpec(enc, 'bart_test', layers, L, img, 3, vocab=V)
+    image, tokens, target = R.synthetic_sample(spec, B, seed=4, ragged=True)
+    ti, tt = R.shift_tokens(tokens, target)
+    T, D = ti.shape[1], R.BART_ARCHS['bart_test']['d_model']
+    F_, H = R.BART_ARCHS['bart_test']['ffn'], R.BART_ARCHS['bart_test']['heads']
+    p_h, p_a, p_c, p_path, seed = 0.1, 0.15, 0.2, 0.3, 91
+    model.dec_arch = dict(model.dec_arch, dropout=p_h, attention_dropout=p_a, activation_dropout=p_c)
+    model.enc_arch = dict(model.enc_arch, drop_path=p_path)
+    model.to(dev)
+    model.arena.alloc_training_state()
+    plain = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+    model.set_train_dropout(True, seed=seed)
+    e_, d_, _ = model._ensure_engines()
+    assert model._drop == (p_h, seed, p_a, p_c, p_path) and e_.nblocks == sum(R.SWIN_ARCHS[enc]['depths'])
+    losses = []
+    for step in range(2):
+        spec_d = ops.DropSpec(p_h, seed, step, p_a, p_c, p_path)
+
+        def hidden(site, t):
+            keep = ops.dropout_mask(t.numel(), spec_d, site, dev).cpu().view(t.shape).bool()
+            return torch.where(keep, (t.float() * (1.0 / (1.0 - p_h))).to(t.dtype), torch.zeros_like(t))
+
+        def act(site, t):
+            keep = ops.dropout_mask(t.numel(), spec_d, site, dev, p=p_c).cpu().view(t.shape).bool()
+            return torch.where(keep, (t.float() * (1.0 / (1.0 - p_c))).to(t.dtype), torch.zeros_like(t))
+
+        def attn(site, pr):
+            keep = ops.attn_dropout_mask(pr.shape[0], pr.shape[1], pr.shape[2], pr.shape[3], spec_d, site, dev).cpu().bool()
+            return torch.where(keep, pr * (1.0 / (1.0 - p_a)), torch.zeros_like(pr))
+
+        def path(site, t):
+            j = site // 2
+            rate = p_path * j / (e_.nblocks - 1)
+            if rate <= 0:
+                return t
+            sc = torch.empty(B, device=dev)
+            ops.droppath_scale(sc, rate, spec_d, site)
+            return (t.float() * sc.cpu().view(B, *([1] * (t.dim() - 1)))).to(t.dtype)
+        hidden.attn, hidden.act, hidden.path = attn, act, path
+        op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        oloss = R.cruller_loss(op, spec, image, ti, tt, 'bf16', drop=hidden)
+        oloss.backward()
+        model.arena.g.zero_()
+        loss = float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev)))
+        model.backward()
+        losses.append(loss)
+        assert abs(loss - float(oloss)) / float(oloss) < 1e-3, (step, loss, float(oloss))
+        worst = sorted(((rel(model.arena.grad(k), op[k].grad), k) for k in params if not k.endswith('k_proj.bias')), reverse=True)
+        assert worst[0][0] < 5e-2, worst[:5]
+        tot = torch.sqrt(sum((op[k].grad.float() ** 2).sum() for k in params))
+        assert abs(float(model.arena.g.norm()) - float(tot)) / float(tot) < 2e-2
+    assert abs(losses[0] - plain) > 1e-4 * plain and abs(losses[0] - losses[1]) > 1e-5 * plain
+    keep = ops.attn_dropout_mask(2, 2, 64, 96, ops.DropSpec(0, seed, 0, p_attn=0.25), 200, dev).float().mean()
+    assert abs(float(keep) - 0.75) < 0.02                               # the hash keeps 1 - p of the elements
+    model.set_train_dropout(False)
+    assert float(model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev))) == plain
+    model.set_train_dropout(True, seed=seed)
+    model.forward_loss(image.to(dev), ti.to(dev), tt.to(dev))          # masks set, no backward ...
+    clean = model(image.to(dev), ti.to(dev)).logits.float().clone()     # ... forward() and the eval paths still see none of them
+    model.set_train_dropout(False)
+    assert torch.equal(model(image.to(dev), ti.to(dev)).logits.float(), clean)
+
+
 def test_task_train_steps_vs_oracle_trainer(dev):
     """3 optimiser updates with clip-norm + warmup cosine LR + grad accumulation 2: loss trajectory vs the oracle."""
     from oracle import ref_cpu as R
