@@ -285,7 +285,9 @@ def main():
     cfg = TaskCrullerPretrainCfg(model_name=args.model, dtype='bfloat16', num_intervals=30, num_warmup_intervals=1, eval_frequency=10 ** 9,
                                  opt=OptimizationCfg(learning_rate=3e-4, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm'),
                                  tokenizer=TokenizerCfg(name=BYTE_TOKENIZER),   # synthetic token ids: only vocab size + special ids matter
-                                 graph_step={'auto': None, 'on': True, 'off': False}[args.graph_step])
+                                 # the live roofline brackets kernel launches with HIP events, which cannot be read back from inside a
+                                 # graph replay: 'auto' keeps eager launches whenever the roofline leg is on
+                                 graph_step={'auto': None if args.no_roofline else False, 'on': True, 'off': False}[args.graph_step])
     cfg.model.image_encoder.pretrained = False    # random-init weights of the named architecture (no checkpoints offline): stated in `data`
     cfg.model.text_decoder.pretrained = False
     task = TaskCrullerPretrain(cfg, env)

@@ -26,6 +26,8 @@ int g_crl_prof_on = 0;
 
 extern "C" void crl_prof_mark(int id, int phase, void* stream, double work) {
   if (!g_crl_prof_on) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;   // events recorded into a graph cannot be timed
   if (phase == 0) {
     if (g_prof_used >= g_prof.size()) return;          // pool exhausted: later launches go untimed
     ProfRec& r = g_prof[g_prof_used];

@@ -860,7 +860,7 @@ def test_head_dim_is_checked():
         BartEngine(dict(d_model=128, heads=4, ffn=256, ln_eps=1e-5), 1, 100, 16, ParamArena(), '', Buffers('cpu'))
     hip.load()
     with pytest.raises(hip.HipLibraryError, match='head_dim is 64'):   # row stride 64 cannot hold 2 heads of 64 channels
-        hip.call('crl_attn_fwd', 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 1, 2, 8, 8, 0.125, 0, None)
+        hip.call('crl_attn_fwd', 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 1, 2, 8, 8, 0.125, 0, 0.0, 0, 0, 0, None)
 
 
 # ------------------------------------------------------------------------------------------- DeviceEnv under torchrun, one rank
