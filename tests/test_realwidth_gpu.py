@@ -194,6 +194,9 @@ def test_cfg1_real_width_swin_tiny_bart_base_vs_oracle(dev):
     images, 128-token targets, batch 2: loss and every parameter gradient against the oracle.  C = 96 is the only user of the
     K % 64 != 0 branch of the 128x128 GEMM kernel (K = 96 -> 32-deep K tiles)."""
     from oracle import ref_cpu as R
+    import os
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # many small CPU ops (window attention on 49-token windows): 256 threads only add fork / join time
     enc, dec = 'swin_tiny_patch4_window7_224', BART_B
     img, L, B = (224, 224), 128, 2
     model, spec, params = _build_pair(dev, enc, img, 'RGB', dec, 2, L, seed=15)
@@ -209,6 +212,7 @@ def test_cfg1_real_width_swin_tiny_bart_base_vs_oracle(dev):
     assert abs(loss - oloss) / oloss < 1e-3, (loss, oloss)
     model.backward()
     worst = _compare_grads(model, ograds, 5e-2, 2e-2)
+    torch.set_num_threads(nthreads)
     print(f'\n[a\'] cfg-1 real width: loss hip {loss:.6f} oracle {oloss:.6f}; worst grad rel-L2 {worst[0]}')
 
 
