@@ -85,7 +85,7 @@ def time_kernel(fn, iters=3):
     return e0.elapsed_time(e1) / iters
 
 
-KERNEL_NAMES = ['attn_fwd_kernel<false>', 'attn_fwd_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
+KERNEL_NAMES = ['attn_fwd_pre_kernel<false>', 'attn_fwd_pre_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
                 'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>', 'attn_bwd_fused_kernel<0>', 'attn_dq_reduce_kernel']
 
 
@@ -192,11 +192,11 @@ def dominant_kernel_roofline(task, B):
     h2, act, pre = T['vit.b0.ln2.y16'], torch.empty_like(T['vit.b0.act']), torch.empty_like(T['vit.b0.pre'])
     w1, b1 = enc.W('blocks.0.mlp.fc1.weight'), enc.P('blocks.0.mlp.fc1.bias')
     cand = {}
-    t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False))
-    cand['attn_fwd_kernel<false> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
+    t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False, q_prescaled=True))
+    cand['attn_fwd_pre_kernel<false> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
     from pixparse_amd import hip
     bwd = lambda: ops.attn_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do, lse, delta,
-                               dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False)
+                               dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False, q_prescaled=True)
     bwd()   # fills the delta / lse row constants once
     # algorithmic backward = 4 products (dV, dP, dK, dQ = 2x forward); the dK/dV pass carries 3 of them (+ S recomputed),
     # the dQ pass 1 (+ S, dP recomputed): executed 4 and 3 products.
@@ -391,7 +391,7 @@ def main():
                 enc_ = m._engines[0]
                 tiles = (enc_.N + 127) // 128
                 grid = tiles * args.batch * enc_.heads * 256
-                n_operands = {'attn_fwd_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6}[live_prof['kernel']]
+                n_operands = {'attn_fwd_pre_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6}[live_prof['kernel']]
                 algo = n_operands * args.batch * enc_.N * enc_.D * 2
             traffic, src = pmc_traffic(live_prof['kernel'], grid)
             if traffic is not None:

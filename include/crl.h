@@ -69,7 +69,11 @@ int crl_gemm_set_reserved_cus(int n);
 int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
-                  const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream);
+                  const float* resid, int64_t ldr, float colscale, int64_t colscale_cols, void* ws, size_t ws_bytes, void* stream);
+/* colscale / colscale_cols (CRL_EPI_BF16 only; 0 columns = off): C[:, 0:colscale_cols] = bf16((v + b) * colscale) -- ONE rounding.  Lets
+ * the q part of a q|k|v projection leave the GEMM as q * softmax_scale * log2(e), which is what crl_attn_fwd / crl_attn_bwd take
+ * with q_prescaled = 1 (timm Attention: q * self.scale; SDPA: the scale argument): the flash kernels then get base-2 logits straight
+ * out of the Q.K^T MFMAs, with no multiply per score. */
 
 /* Single-query attention over a KV cache (generation; replaces F.scaled_dot_product_attention inside transformers'
  * BartAttention for a [B, 1, D] query, reference utils/ocr_utils.py:181-187 -> text_decoder_hf.py:39-45):
@@ -127,8 +131,12 @@ int crl_layernorm_bwd(const float* dy_f32, const void* dy_bf16, const float* x, 
  * diagonal bottom-right (key j visible to query i iff j <= i + Nk - Nq). */
 int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
-                 float* lse, int B, int H, int Nq, int Nk, float scale, int causal,
+                 float* lse, int B, int H, int Nq, int Nk, float scale, int causal, int q_prescaled,
                  float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* stream);
+/* q_prescaled = 1: q holds q * scale * log2(e) (crl_gemm_bf16 colscale on the q columns of the projection).  The forward then runs the
+ * seeded / lazy-maximum kernel (base-2 logits straight from the Q.K^T MFMAs; `scale` unused); the backward needs the same flag AND the
+ * true `scale` (it stores dQ as the gradient of the unscaled projection output, as without prescaling).  lse is the natural-log
+ * log-sum-exp of the true scores either way. */
 /* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators).
  * dq/dk/dv strides as q/k/v.  Two forms (same results up to bf16 rounding of dq; both deterministic, no float atomics):
  *   two-pass    dQ pass (recomputes S, dP; produces the row constants) then dK/dV pass (recomputes S, dP): 7 MFMA products per tile;
@@ -146,7 +154,7 @@ int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
                  void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
                  void* dv, int64_t dv_bs, int64_t dv_rs,
-                 int B, int H, int Nq, int Nk, float scale, int causal,
+                 int B, int H, int Nq, int Nk, float scale, int causal, int q_prescaled,
                  float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* ws, size_t ws_bytes, void* stream);
 /* drop_p > 0: attention-probability dropout (transformers BartAttention / SDPA dropout_p = config.attention_dropout, hf:240-252:
  * softmax, THEN dropout of the probabilities, then P.V).  Element (b, h, q, k) is kept iff a 32-bit hash of its index keyed by

@@ -43,6 +43,7 @@ struct AttnArgs {
   // The mask is never stored: the forward and both backward passes re-evaluate it (DROP template argument of the kernels).
   uint32_t drop_thr, drop_key;
   float drop_scale;
+  float dq_mul;        // factor on dQ at the store: the softmax scale (with q_prescaled the kernels' own `scale` is ln 2, see crl_attn_bwd)
 };
 
 // keep decision of attention dropout: a 32-bit integer hash (multiply / xor-shift rounds, full avalanche) of the element index, keyed by
@@ -246,6 +247,163 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
 #if FWD_ONES
   if (hh) l = 0.f;
 #endif
+  l += swap32(l);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (qabs < a.Nq) {
+    u16* op = a.out + b * a.o_bs + (int64_t)qabs * a.o_rs + h * 64;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dv = 8 * g4 + 4 * hh;
+      *reinterpret_cast<uint2*>(op + dv) = uint2{pack_bf2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv), pack_bf2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv)};
+      *reinterpret_cast<uint2*>(op + 32 + dv) = uint2{pack_bf2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv), pack_bf2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv)};
+    }
+    if (hh == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qabs] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : -INFINITY;
+  }
+}
+
+// ======================================================================================= forward, q prescaled (base-2 logits)
+// The query operand already carries softmax_scale * log2(e) (the q part of the q|k|v projection leaves the GEMM that way:
+// crl_gemm_bf16 colscale), so S^T = K.Q^T comes out of the MFMAs in base-2 logits.  attn_fwd_kernel above spends, per 32-query x
+// 64-key block, 768 issue cycles for 512 MFMA cycles (it is VALU-issue bound): 32 v_exp (256), 32 fma for s c - m (128), 32 adds for
+// the row sum (128), 16 v_max3 (64), 16 conversions (64) + the MFMAs' own 128.  Here
+//   * the running reference -m is the INITIAL ACCUMULATOR of the S chains (a 16-register tuple holding -m in every register: the query
+//     sits on the lane, so one value serves all 16), i.e. the subtraction costs nothing;
+//   * the reference is moved lazily (guide T13): a tile takes the fast path -- no row maximum at all -- and checks afterwards that its
+//     row sums stayed below 2^30 (probabilities up to 2^30 instead of <= 1 are harmless in fp32 / bf16: same relative precision);
+//     the first tile, and any tile that fails the check (Inf / NaN included), recomputes its scores from a zero accumulator, takes the
+//     true row maximum and re-centres O, l and the seed exactly like the kernel above;
+// which leaves 32 v_exp + 32 adds + 16 conversions per block on the fast path.  Same results up to the rounding of p (the reference
+// only shifts every probability of a row and its sum by the same power of two).
+template <bool CAUSAL, bool DROP = false>
+__global__ __launch_bounds__(256, 3) void attn_fwd_pre_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31, hh = lane >> 5;
+  int bh, qt;
+  block_to_bh_tile(blockIdx.x, a.nqt, a.B * a.H, bh, qt);
+  const int b = bh / a.H, h = bh % a.H;
+  const int off = a.Nk - a.Nq;
+
+  const u16* qp = a.q + b * a.q_bs + h * 64;
+  const u32x4 rk = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const uint32_t sbase = lds_addr_of(smem);
+  const LaneAddr la = make_lane_addr(lane);
+  const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
+
+  const int q0 = qt * 128 + wave * 32;
+  const bool wave_live = q0 < a.Nq;
+  const int qrow = min(q0 + qi, a.Nq - 1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)qrow * a.q_rs + 16 * ks + 8 * hh);
+
+  int kend = a.Nk;
+  if (CAUSAL) kend = min(a.Nk, qt * 128 + 127 + off + 1);
+  const int nt = kend > 0 ? (kend + 63) / 64 : 0;
+
+  f32x16 o0 = zero16(), o1 = zero16(), seed = zero16();     // seed = -m in every register
+  float m = -INFINITY, l = 0.f;                             // base-2 reference of this query row, per-lane partial row sum
+  const int qabs = q0 + qi;
+  constexpr float FAST_LIMIT = 1073741824.f;                // 2^30
+
+  auto stage = [&](int buf, int kt) {
+    stage64(rk, sbase + buf * 16384, sk, kt * 64, a.k_rs, wave);
+    stage64(rv, sbase + buf * 16384 + 8192, sv, kt * 64, a.v_rs, wave);
+  };
+  auto tile = [&](auto bufc, int kt) {
+    constexpr int BUFI = decltype(bufc)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nt) stage(BUFI ^ 1, kt + 1);
+    if (!wave_live) return;
+    const char* kl = smem + BUFI * 16384;
+    const char* vl = kl + 8192;
+    const int k0 = kt * 64;
+    const bool need_mask = (k0 + 64 > a.Nk) || (CAUSAL && (k0 + 63 > q0 + off));
+    const int lim = CAUSAL ? min(a.Nk - 1, qabs + off) : a.Nk - 1;
+    auto scores = [&](f32x16& s0, f32x16& s1, const f32x16& init) {
+      __builtin_amdgcn_s_setprio(PRIO_MFMA);
+      s0 = mfma32(frag_row(kl, la, 0, 0), qf[0], init);
+      s1 = mfma32(frag_row(kl, la, 32, 0), qf[0], init);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) {
+        s0 = mfma32(frag_row(kl, la, 0, ks), qf[ks], s0);
+        s1 = mfma32(frag_row(kl, la, 32, ks), qf[ks], s1);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + acc_row(r, hh);
+          if (key > lim) s0[r] = -INFINITY;
+          if (key + 32 > lim) s1[r] = -INFINITY;
+        }
+      }
+    };
+    f32x16 s0, s1;
+    float ps = 0.f;
+    bool slow = kt == 0;
+    if (!slow) {
+      scores(s0, s1, seed);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+        ps += s0[r] + s1[r];
+      }
+      slow = __any(!(ps < FAST_LIMIT));      // also catches Inf and NaN
+    }
+    if (slow) {
+      scores(s0, s1, zero16());
+      float mx = max3f(s0[0], s1[0], -INFINITY);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = max3f(mx, s0[r], s1[r]);
+      mx = max3f(mx, swap32(mx), -INFINITY);
+      const float m_new = fmaxf(m, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      if (__any(m_new != m)) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; seed[r] = -m_use; }
+        m = m_new;
+      }
+      ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_use);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_use);
+        ps += s0[r] + s1[r];
+      }
+    }
+    l += ps;
+    if constexpr (DROP) {      // the row sum is of the UNdropped probabilities (softmax, then dropout); P.V uses the dropped ones
+      const uint32_t xb = ((uint32_t)bh * (uint32_t)a.Nq + (uint32_t)qabs) * (uint32_t)a.Nk + (uint32_t)(k0 + 4 * hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t x = xb + (uint32_t)((r & 3) + 8 * (r >> 2));
+        s0[r] = attn_drop_hash(x, a.drop_key) >= a.drop_thr ? s0[r] * a.drop_scale : 0.f;
+        s1[r] = attn_drop_hash(x + 32u, a.drop_key) >= a.drop_thr ? s1[r] * a.drop_scale : 0.f;
+      }
+    }
+    __builtin_amdgcn_s_setprio(PRIO_MFMA);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 p0 = acc_frag(s0, s), p1 = acc_frag(s1, s);
+      o0 = mfma32(frag_tr(vl, la, 16 * s, 0), p0, o0);
+      o1 = mfma32(frag_tr(vl, la, 16 * s, 1), p0, o1);
+      o0 = mfma32(frag_tr(vl, la, 32 + 16 * s, 0), p1, o0);
+      o1 = mfma32(frag_tr(vl, la, 32 + 16 * s, 1), p1, o1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (nt > 0) stage(0, 0);
+  for (int kt = 0; kt < nt; kt += 2) {
+    tile(ic<0>{}, kt);
+    if (kt + 1 < nt) tile(ic<1>{}, kt + 1);
+  }
   l += swap32(l);
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (qabs < a.Nq) {
@@ -540,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   }
   if (qabs < a.Nq) {
     u16* dqp = a.dq + b * a.dq_bs + (int64_t)qabs * a.dq_rs + h * 64;
-    const float sc = a.scale;
+    const float sc = a.dq_mul;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d = 8 * g4 + 4 * hh;
@@ -838,7 +996,7 @@ int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) 
 
 extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                             const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
-                            float* lse, int B, int H, int Nq, int Nk, float scale, int causal,
+                            float* lse, int B, int H, int Nq, int Nk, float scale, int causal, int q_prescaled,
                             float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site, void* stream) {
   const char* who = "crl_attn_fwd";
   {
@@ -860,7 +1018,11 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   // algorithmic FLOPs: QK^T and PV, 2 x 2 x Nq x Nk x 64 per head (a causal mask halves them when Nq == Nk)
   const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
   CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
-  if (drop) {
+  if (q_prescaled) {       // base-2 logits straight from the MFMAs: the seeded / lazy-maximum kernel (`scale` is not used)
+    if (drop) { if (causal) attn_fwd_pre_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a); else attn_fwd_pre_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a); }
+    else if (causal) attn_fwd_pre_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
+    else attn_fwd_pre_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a);
+  } else if (drop) {
     if (causal) attn_fwd_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a);
     else attn_fwd_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a);
   } else if (causal) attn_fwd_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
@@ -897,7 +1059,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
                             const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                             const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,
                             void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs,
-                            void* dv, int64_t dv_bs, int64_t dv_rs, int B, int H, int Nq, int Nk, float scale, int causal,
+                            void* dv, int64_t dv_bs, int64_t dv_rs, int B, int H, int Nq, int Nk, float scale, int causal, int q_prescaled,
                             float drop_p, uint64_t drop_seed, uint32_t drop_step, uint32_t drop_site,
                             void* ws, size_t ws_bytes, void* stream) {
   const char* who = "crl_attn_bwd";
@@ -915,7 +1077,12 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
   a.do_bs = do_bs; a.do_rs = do_rs; a.dq_bs = dq_bs; a.dq_rs = dq_rs; a.dk_bs = dk_bs; a.dk_rs = dk_rs; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = scale;
+  // q_prescaled: q holds q * scale * log2(e).  The kernels recompute  S' = q'.k (base-2 logits), so their own scale is ln 2:
+  //   c = scale_k log2(e) = 1 (P = exp2(S' - lse log2e)), the S seed -lse / scale_k = -lse log2(e), dK = ln 2 (dS^T q') = scale (dS^T q)
+  // (d logit' = ln 2 dS); dQ is stored as the gradient of the UNscaled projection output, scale dS.K, exactly as without prescaling
+  // (the GEMM epilogue's factor is part of the layer: d(x W + b) = scale log2(e) dq' = scale dS.K).
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.causal = causal; a.scale = q_prescaled ? LN2 : scale;
+  a.dq_mul = scale;
   a.nqt = (Nq + 127) / 128; a.nkt = (Nk + 127) / 128;
   if (set_drop(who, a, drop_p, drop_seed, drop_step, drop_site)) return -1;
   const bool drop = a.drop_thr != 0;
@@ -955,7 +1122,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     CRL_LAUNCH_CHECK("crl_attn_bwd(fused)");
     const int64_t n8 = (int64_t)B * Nq * (H * 64 / 8);
     CRL_PROF_START(CRL_K_ATTN_DQ_REDUCE, stream, 0.0);
-    attn_dq_reduce_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>((const u16*)ws, slab_stride, nslab, (u16*)dq, dq_bs, dq_rs, B, Nq, H * 64, scale);
+    attn_dq_reduce_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>((const u16*)ws, slab_stride, nslab, (u16*)dq, dq_bs, dq_rs, B, Nq, H * 64, a.dq_mul);
     CRL_PROF_STOP(CRL_K_ATTN_DQ_REDUCE, stream);
     CRL_LAUNCH_CHECK("crl_attn_bwd(dq reduce)");
     return 0;

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
         }
       }
       if constexpr (EPI == CRL_EPI_BF16) {
-        uint2 o{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        const float f = n < g.colscale_cols ? g.colscale : 1.f;
+        uint2 o{pack_bf2(v[0] * f, v[1] * f), pack_bf2(v[2] * f, v[3] * f)};
         *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = o;
       } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
         float h[4], y[4];
@@ -158,7 +159,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, s
 // few remainder rows of the wave-quantisation split when their contraction is long (see crl_gemm_bf16)
 template <int EPI>
 __global__ void splitk_reduce_epi_kernel(const float* __restrict__ ws, int nsplit, size_t slab, int M, int N, const float* __restrict__ bias,
-                                         void* __restrict__ C, int ldc, const float* __restrict__ resid, int ldr) {
+                                         void* __restrict__ C, int ldc, const float* __restrict__ resid, int ldr, float colscale = 1.f, int colscale_cols = 0) {
   const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (idx >= (size_t)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx % N);
@@ -172,7 +173,8 @@ __global__ void splitk_reduce_epi_kernel(const float* __restrict__ ws, int nspli
     s.x += round_bf(b.x); s.y += round_bf(b.y); s.z += round_bf(b.z); s.w += round_bf(b.w);
   }
   if constexpr (EPI == CRL_EPI_BF16) {
-    *reinterpret_cast<uint2*>((u16*)C + (size_t)m * ldc + n) = uint2{pack_bf2(s.x, s.y), pack_bf2(s.z, s.w)};
+    const float f = n < colscale_cols ? colscale : 1.f;
+    *reinterpret_cast<uint2*>((u16*)C + (size_t)m * ldc + n) = uint2{pack_bf2(s.x * f, s.y * f), pack_bf2(s.z * f, s.w * f)};
   } else {
     const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)m * ldr + n);
     *reinterpret_cast<float4*>((float*)C + (size_t)m * ldc + n) = float4{r.x + round_bf(s.x), r.y + round_bf(s.y), r.z + round_bf(s.z), r.w + round_bf(s.w)};
@@ -341,7 +343,9 @@ extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t
 extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                              const void* A, int64_t lda, const void* B, int64_t ldb,
                              const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
-                             const float* resid, int64_t ldr, void* ws, size_t ws_bytes, void* stream) {
+                             const float* resid, int64_t ldr, float colscale, int64_t colscale_cols, void* ws, size_t ws_bytes, void* stream) {
+  CRL_CHECK(colscale_cols == 0 || (epilogue == CRL_EPI_BF16 && colscale_cols > 0 && colscale_cols <= N && (colscale_cols % 4) == 0),
+            "crl_gemm_bf16: the column scale applies to the first colscale_cols (multiple of 4, <= N) columns of the plain bf16 epilogue");
   CRL_CHECK(M > 0 && N > 0 && K > 0, "crl_gemm_bf16: empty problem %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
   CRL_CHECK(A && B && C, "crl_gemm_bf16: null operand");
   CRL_CHECK((N % 4) == 0 && (ldc % 4) == 0, "crl_gemm_bf16: N (%lld) and ldc (%lld) must be multiples of 4", (long long)N, (long long)ldc);
@@ -377,6 +381,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc; a.ldaux = (int)ldaux; a.ldr = (int)ldr;
   a.a_bytes = (uint32_t)ab; a.b_bytes = (uint32_t)bb;
   a.sched = nullptr;
+  a.colscale = colscale; a.colscale_cols = (int)colscale_cols;
   a.ntm = (int)((M + BM - 1) / BM); a.ntn = (int)((N + BN - 1) / BN);
   hipStream_t s = as_stream(stream);
   Plan p = plan_gemm(layout, epilogue, M, N, K, ws != nullptr);
@@ -431,7 +436,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
       if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
       const unsigned blocks = (unsigned)(((size_t)rem * N / 4 + 255) / 256);
       if (epilogue == CRL_EPI_BF16)
-        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0);
+        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
       else
         splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, rest.resid, (int)ldr);
       CRL_LAUNCH_CHECK("crl_gemm_bf16(remainder reduce)");
@@ -453,7 +458,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
       if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
       const unsigned blocks = (unsigned)(((size_t)M * N / 4 + 255) / 256);
       if (epilogue == CRL_EPI_BF16)
-        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, nullptr, 0);
+        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
       else
         splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, a.resid, (int)ldr);
       CRL_LAUNCH_CHECK("crl_gemm_bf16(few-tiles split reduce)");

@@ -15,6 +15,8 @@ struct GemmArgs {
   int kchunk;            // K tiles per split (gridDim.y splits; split s writes slab s of C)
   size_t slab_stride;    // elements between slabs
   uint32_t* sched;       // dynamic tile scheduler state of this launch (persistent launches only, else nullptr): see TileSched
+  float colscale;        // bf16 epilogue: output columns [0, colscale_cols) are multiplied by colscale before the rounding (0 columns = off);
+  int colscale_cols;     // the q part of a fused q|k|v projection leaves the GEMM as q * scale * log2(e) (crl_attn_* with q_prescaled)
 };
 
 // ---- dynamic tile scheduler of the persistent kernels -------------------------------------------------------------------------

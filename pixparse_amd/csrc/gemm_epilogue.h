@@ -109,6 +109,12 @@ __device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc
         for (int r = 0; r < 4; ++r) bw[pr][j][r] = round_bf(__uint_as_float(braw[pr][j][r]));
   }
 
+  // column scale of the plain bf16 epilogue (q columns of a q|k|v projection): per 16-column strip of the lane's math layout
+  float cs[2][2];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cs[pr][j] = (n0e + QN * pr + 32 * wc + 16 * j + 4 * lq) < g.colscale_cols ? g.colscale : 1.f;
   if constexpr (BF16_OUT) {
     // bf16 outputs: after swap_strips a lane owns 8 consecutive columns of a 32-column strip pair -> one 16-byte access per (qm, i, pr)
     uint32_t cC[2], cA[2];
@@ -147,6 +153,7 @@ __device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc
           const f32x4 a4 = acc[qm][pr][i][j];
           v[j][0] = f32x2{a4[0], a4[1]}; v[j][1] = f32x2{a4[2], a4[3]};
           if constexpr (BIAS_EPI) { v[j][0] += f32x2{bw[pr][j][0], bw[pr][j][1]}; v[j][1] += f32x2{bw[pr][j][2], bw[pr][j][3]}; }
+          if constexpr (EPI == CRL_EPI_BF16) { v[j][0] *= cs[pr][j]; v[j][1] *= cs[pr][j]; }
         }
         uint32_t x0, x1, y0, y1;
         if constexpr (EPI == CRL_EPI_BF16) {
@@ -372,6 +379,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
             uint32_t x0, x1, y0, y1;
             u16* crow = (u16*)g.C + mc * g.ldc + nw[pr];
             if constexpr (EPI == CRL_EPI_BF16) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const float f = (n0e + QN * pr + 32 * wc + 16 * j + 4 * lq) < g.colscale_cols ? g.colscale : 1.f;
+                v[j][0] *= f; v[j][1] *= f; v[j][2] *= f; v[j][3] *= f;
+              }
               x0 = pack_bf2(v[0][0], v[0][1]); x1 = pack_bf2(v[0][2], v[0][3]);
               y0 = pack_bf2(v[1][0], v[1][1]); y1 = pack_bf2(v[1][2], v[1][3]);
               swap_strips(x0, x1, y0, y1);
@@ -434,7 +446,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
             }
           }
           if constexpr (EPI == CRL_EPI_BF16) {
-            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            const float f = n < g.colscale_cols ? g.colscale : 1.f;
+            *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(v[0] * f, v[1] * f), pack_bf2(v[2] * f, v[3] * f)};
           } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
             float h[4], y[4];
 #pragma unroll

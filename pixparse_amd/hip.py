@@ -26,7 +26,7 @@ SIGNATURES = {
     'crl_gemm_set_policy': (I, [I]),
     'crl_gemm_set_schedule': (I, [I]),
     'crl_gemm_set_reserved_cus': (I, [I]),
-    'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, P, Z, P]),
+    'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, F, L, P, Z, P]),
     'crl_attn_decode_ws_bytes': (Z, [I, I, I]),
     'crl_attn_decode': (I, [P, L, P, L, L, P, L, L, P, L, I, I, I, F, P, P, L, P, Z, P]),
     'crl_linear_skinny_bf16': (I, [I, I, L, L, P, L, P, L, P, P, L, P, L, P, L, P]),
@@ -35,10 +35,10 @@ SIGNATURES = {
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),
     'crl_layernorm_bwd_ws_bytes': (Z, [L]),
     'crl_layernorm_bwd': (I, [P, P, P, P, P, P, L, L, P, I, P, P, P, P, I, P, P]),
-    'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, F, U64, U32, U32, P]),
+    'crl_attn_fwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, F, I, I, F, U64, U32, U32, P]),
     'crl_attn_dropout_mask': (I, [P, I, I, I, I, F, U64, U32, U32, P]),
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
-                         I, I, I, I, F, I, F, U64, U32, U32, P, Z, P]),
+                         I, I, I, I, F, I, I, F, U64, U32, U32, P, Z, P]),
     'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
     'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),

@@ -157,11 +157,12 @@ class ViTEngine(_Base):
             bp, k = f'blocks.{i}.', f'b{i}'
             _, h1 = self.ln_fwd(bp + 'norm1', x, k + '.ln1', eps)
             qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
-            ops.linear_fwd(h1, self.W(bp + 'attn.qkv.weight'), self.P(bp + 'attn.qkv.bias'), qkv)
+            # the q columns leave the GEMM as q * scale * log2(e) (one rounding): the flash kernels get base-2 logits from the MFMAs
+            ops.linear_fwd(h1, self.W(bp + 'attn.qkv.weight'), self.P(bp + 'attn.qkv.bias'), qkv, colscale=scale * ops.LOG2E, colscale_cols=D)
             q3 = qkv.view(B, N, 3 * D)
             o = self.buf(k + '.o', (M, D), BF16)
             lse = self.buf(k + '.lse', (B, self.heads, N), F32)
-            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:3 * D], o.view(B, N, D), lse, self.heads, scale, False)
+            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:3 * D], o.view(B, N, D), lse, self.heads, scale, False, q_prescaled=True)
             x2 = self.buf(k + '.x2', (M, D), F32)
             ops.linear_fwd(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, EPI_F32_RESID, resid=x)
             _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
@@ -215,7 +216,7 @@ class ViTEngine(_Base):
             self.lin_wgrad(bp + 'attn.proj', gb, o, has_bias=False)
             q3, dq3 = qkv.view(B, N, 3 * D), dqkv.view(B, N, 3 * D)
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do.view(B, N, D), lse, delta,
-                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], self.heads, scale, False)
+                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], self.heads, scale, False, q_prescaled=True)
             ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
             self.lin_wgrad(bp + 'attn.qkv', dqkv, h1)
             self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb,    # dx := d(xin) = d(x3 of block i-1)
@@ -527,22 +528,26 @@ class BartEngine(_Base):
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
-            ops.linear_fwd(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), qkv)
+            ops.linear_fwd(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), qkv,
+                           colscale=scale * ops.LOG2E, colscale_cols=D)          # q leaves the projection as q * scale * log2(e)
             q3 = qkv.view(B, T, 3 * D)
             o1 = self.buf(k + '.o1', (M, D), BF16)
             lse1 = self.buf(k + '.lse1', (B, H, T), F32)
-            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True, drop=drop, site=200 + 2 * i)
+            ops.attn_fwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o1.view(B, T, D), lse1, H, scale, True, drop=drop, site=200 + 2 * i,
+                         q_prescaled=True)
             t1 = self.buf(k + '.t1', (M, D), F32)
             self._branch(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, h, 1 + 3 * i)
             h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
             q2 = self.buf(k + '.q2', (M, D), BF16)
-            ops.linear_fwd(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
+            ops.linear_fwd(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2,
+                           colscale=scale * ops.LOG2E, colscale_cols=D)
             kv2 = self.buf(k + '.kv2', (Me, 2 * D), BF16)
             ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
             kv3 = kv2.view(B, S, 2 * D)
             o2 = self.buf(k + '.o2', (M, D), BF16)
             lse2 = self.buf(k + '.lse2', (B, H, T), F32)
-            ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False, drop=drop, site=201 + 2 * i)
+            ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False, drop=drop, site=201 + 2 * i,
+                         q_prescaled=True)
             t2 = self.buf(k + '.t2', (M, D), F32)
             self._branch(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, h1, 2 + 3 * i)
             h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
@@ -720,7 +725,7 @@ class BartEngine(_Base):
             self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'), has_bias=False)
             kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
             ops.attn_bwd(g('.q2').view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], g('.o2').view(B, T, D), do.view(B, T, D), g('.lse2'), delta,
-                         dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False, drop=drop, site=201 + 2 * i)
+                         dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False, drop=drop, site=201 + 2 * i, q_prescaled=True)
             ops.linear_dgrad(dq2, self.W(lp + 'encoder_attn.q_proj.weight'), dhb)
             self.lin_wgrad(lp + 'encoder_attn.q_proj', dq2, g('.ln1.y16'))
             # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
@@ -733,7 +738,7 @@ class BartEngine(_Base):
             self.lin_wgrad(lp + 'self_attn.out_proj', dtb, g('.o1'), has_bias=False)
             q3, dq3 = g('.qkv').view(B, T, 3 * D), dqkv.view(B, T, 3 * D)
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
-                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True, drop=drop, site=200 + 2 * i)
+                         dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True, drop=drop, site=200 + 2 * i, q_prescaled=True)
             ops.linear_dgrad(dqkv, self.fw('w', lp, 'self_attn', 'q_proj', 3), dyb)
             ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True)
             ops.colsum(dqkv, self.fb('g', lp, 'self_attn', 'q_proj', 3), True)

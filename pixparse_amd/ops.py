@@ -32,7 +32,7 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
          C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
-         ldaux: int = 0, resid: Optional[torch.Tensor] = None, ldr: int = 0) -> None:
+         ldaux: int = 0, resid: Optional[torch.Tensor] = None, ldr: int = 0, colscale: float = 1.0, colscale_cols: int = 0) -> None:
     _chk(A, BF16, 'gemm A')
     _chk(B, BF16, 'gemm B')
     ws = None
@@ -40,16 +40,18 @@ def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: in
     if wsb:
         ws = _gemm_scratch.get(wsb, A.device)
     hip.call('crl_gemm_bf16', layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(C), ldc, _p(aux), ldaux,
-             _p(resid), ldr, _p(ws), wsb, _stream())
+             _p(resid), ldr, float(colscale), int(colscale_cols), _p(ws), wsb, _stream())
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16,
-               aux: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
-    """out[M, N] = x[M, K] @ w[N, K]^T (+bias) with the epilogue; x, w bf16 row-major 2-D (may be row-strided)."""
+               aux: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, n: Optional[int] = None,
+               colscale: float = 1.0, colscale_cols: int = 0) -> None:
+    """out[M, N] = x[M, K] @ w[N, K]^T (+bias) with the epilogue; x, w bf16 row-major 2-D (may be row-strided).
+    colscale / colscale_cols: the first colscale_cols output columns are multiplied by colscale before the bf16 rounding (q of q|k|v)."""
     M, K = x.shape
     N = n if n is not None else w.shape[0]
     gemm(NT, epi, M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0), bias, aux,
-         aux.stride(0) if aux is not None else 0, resid, resid.stride(0) if resid is not None else 0)
+         aux.stride(0) if aux is not None else 0, resid, resid.stride(0) if resid is not None else 0, colscale, colscale_cols)
 
 
 SKINNY_MAX_ROWS = 16
@@ -148,14 +150,18 @@ def _drop_args(drop, site):
     return float(drop.p_attn), drop.seed, drop.step, int(site)
 
 
-def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool, drop=None, site: int = 0) -> None:
+LOG2E = 1.4426950408889634
+
+
+def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool, drop=None, site: int = 0, q_prescaled: bool = False) -> None:
     """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32.
-    drop (DropSpec with p_attn > 0) + site: dropout of the attention probabilities (the backward call must pass the same pair)."""
+    drop (DropSpec with p_attn > 0) + site: dropout of the attention probabilities (the backward call must pass the same pair).
+    q_prescaled: q already carries scale * log2(e) (linear_fwd(..., colscale=scale * LOG2E, colscale_cols=D)): the faster forward kernel."""
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o)
     hip.call('crl_attn_fwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o), _p(lse),
-             B, heads, Nq, Nk, float(scale), int(causal), *_drop_args(drop, site), _stream())
+             B, heads, Nq, Nk, float(scale), int(causal), int(q_prescaled), *_drop_args(drop, site), _stream())
 
 
 def attn_dropout_mask(B: int, H: int, Nq: int, Nk: int, drop, site: int, device) -> torch.Tensor:
@@ -187,7 +193,8 @@ def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) ->
              _stream())
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool, drop=None, site: int = 0) -> None:
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool, drop=None, site: int = 0,
+             q_prescaled: bool = False) -> None:
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)
@@ -195,7 +202,7 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, 
     ws = _attn_scratch.get(wsb, q.device) if wsb else None
     hip.call('crl_attn_bwd', _p(q), *_bs_rs(q), _p(k), *_bs_rs(k), _p(v), *_bs_rs(v), _p(o), *_bs_rs(o),
              _p(d_o), *_bs_rs(d_o), _p(lse), _p(delta), _p(dq), *_bs_rs(dq), _p(dk), *_bs_rs(dk), _p(dv), *_bs_rs(dv),
-             B, heads, Nq, Nk, float(scale), int(causal), *_drop_args(drop, site), _p(ws), wsb, _stream())
+             B, heads, Nq, Nk, float(scale), int(causal), int(q_prescaled), *_drop_args(drop, site), _p(ws), wsb, _stream())
 
 
 def swin_attn_fwd(qkv, table, out, B, Hf, Wf, heads, w, shift, scale) -> None:

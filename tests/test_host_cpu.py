@@ -75,9 +75,9 @@ def test_argument_validation_without_gpu():
     from pixparse_amd import hip
     hip.load()
     with pytest.raises(hip.HipLibraryError, match='multiple of 32'):
-        hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, None, 0, None)
+        hip.call('crl_gemm_bf16', hip.NT, hip.EPI_BF16, 8, 8, 40, 16, 40, 16, 40, None, 16, 8, None, 0, None, 0, 1.0, 0, None, 0, None)
     with pytest.raises(hip.HipLibraryError, match='empty'):
-        hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, 0.0, 0, 0, 0, None)
+        hip.call('crl_attn_fwd', 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 64, 64, 16, 0, 1, 4, 4, 0.125, 0, 0, 0.0, 0, 0, 0, None)
     with pytest.raises(hip.HipLibraryError, match='window'):
         hip.call('crl_swin_attn_fwd', 16, 16, 16, 1, 18, 18, 1, 9, 0, 0.1, None)
 
@@ -860,7 +860,7 @@ def test_head_dim_is_checked():
         BartEngine(dict(d_model=128, heads=4, ffn=256, ln_eps=1e-5), 1, 100, 16, ParamArena(), '', Buffers('cpu'))
     hip.load()
     with pytest.raises(hip.HipLibraryError, match='head_dim is 64'):   # row stride 64 cannot hold 2 heads of 64 channels
-        hip.call('crl_attn_fwd', 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 1, 2, 8, 8, 0.125, 0, 0.0, 0, 0, 0, None)
+        hip.call('crl_attn_fwd', 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 512, 64, 16, 1, 2, 8, 8, 0.125, 0, 0, 0.0, 0, 0, 0, None)
 
 
 # ------------------------------------------------------------------------------------------- DeviceEnv under torchrun, one rank

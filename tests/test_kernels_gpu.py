@@ -35,6 +35,77 @@ def close(a, b, rtol, atol, what=''):
     assert not bad.any(), f'{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (ref max {float(b.abs().max()):.4g})'
 
 
+# ------------------------------------------------------------------------------------------- attention with a prescaled q
+@pytest.mark.parametrize('B,H,Nq,Nk,causal', [(1, 2, 200, 333, False), (2, 1, 130, 130, True), (1, 2, 64, 1500, False), (1, 1, 300, 45, False)])
+def test_attention_q_prescaled(dev, B, H, Nq, Nk, causal):
+    """q_prescaled = 1: q carries softmax_scale * log2(e); the forward is the seeded / lazy-maximum kernel (first tile and any tile whose
+    row sums exceed 2^30 re-centre, every other tile runs without a row maximum).  Forward and backward against fp32 torch on the SAME
+    (prescaled) operands: out, lse, dq (gradient of the UNscaled projection output), dk, dv; and against the unscaled kernels fed the
+    exact same mathematical problem.  A second data set makes later tiles overflow the reference of the first (scores growing along the
+    keys) so that the re-centring path runs in the middle of a row."""
+    from pixparse_amd import ops
+    D, scale = H * 64, 0.125
+    c = scale * ops.LOG2E
+    for growing in (False, True):
+        g = torch.Generator(device=dev).manual_seed(Nq + Nk + int(growing))
+        qraw = torch.randn(B, Nq, D, generator=g, device=dev)
+        k = torch.randn(B, Nk, D, generator=g, device=dev)
+        if growing:         # later keys score ever higher: up to ~2^40 above the first tile's maximum along a row
+            k = k * torch.linspace(0.2, 6.0, Nk, device=dev).view(1, Nk, 1)
+            qraw = qraw.abs() * 1.5
+            k = k.abs()
+        k = k.to(BF16)
+        v, do = (torch.randn(B, t, D, generator=g, device=dev).to(BF16) for t in (Nk, Nq))
+        qpre = (qraw * c).to(BF16)                                # what the projection GEMM's colscale epilogue writes
+        o = torch.empty_like(qpre)
+        lse = torch.empty(B, H, Nq, device=dev)
+        ops.attn_fwd(qpre, k, v, o, lse, H, scale, causal, q_prescaled=True)
+        dq, dk, dv = torch.full_like(qpre, float('nan')), torch.full_like(k, float('nan')), torch.full_like(v, float('nan'))
+        delta = torch.empty(2, B, H, Nq, device=dev)
+        ops.attn_bwd(qpre, k, v, o, do, lse, delta, dq, dk, dv, H, scale, causal, q_prescaled=True)
+        hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2)
+        qproj = (hd(qpre) / c).requires_grad_(True)              # the unscaled projection output whose scaled copy the kernels saw
+        K, V = hd(k).requires_grad_(True), hd(v).requires_grad_(True)
+        z = (qproj * c) @ K.transpose(-1, -2) * math.log(2.0)     # natural-log logits = ln 2 * base-2 logits
+        if causal:
+            mask = torch.ones(Nq, Nk, dtype=torch.bool, device=dev).tril(diagonal=Nk - Nq)
+            z = z.masked_fill(~mask, float('-inf'))
+        out = torch.softmax(z, -1) @ V
+        out.backward(hd(do))
+        back = lambda t: t.transpose(1, 2).reshape(B, -1, D)
+        rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+        assert rel(o, back(out.detach())) < 1e-2, (growing, rel(o, back(out.detach())))
+        assert float((lse - torch.logsumexp(z, -1)).abs().max()) < 3e-3 * max(1.0, float(z.abs().max()) / 50)
+        assert rel(dq, back(qproj.grad)) < 2e-2 and rel(dk, back(K.grad)) < 2e-2 and rel(dv, back(V.grad)) < 2e-2, \
+            (growing, rel(dq, back(qproj.grad)), rel(dk, back(K.grad)), rel(dv, back(V.grad)))
+        if not growing:      # the unscaled kernels on the same problem (q = qpre / c is not bf16-exact: compare at bf16 tolerance)
+            o2 = torch.empty_like(qpre)
+            lse2 = torch.empty_like(lse)
+            ops.attn_fwd((qpre.float() / c).to(BF16), k, v, o2, lse2, H, scale, causal)
+            assert rel(o, o2) < 2e-2
+
+
+def test_gemm_column_scale(dev):
+    """crl_gemm_bf16 colscale: the first colscale_cols columns of the plain bf16 epilogue are multiplied before the rounding -- through
+    the 256x256 kernel, the 128x128 kernel, the remainder rows and the split-contraction reduce"""
+    from pixparse_amd import hip, ops
+    cs = 0.125 * ops.LOG2E
+    for (M, N, K, cols) in [(256 * 5 + 72, 1536, 256, 512), (300, 384, 128, 128), (256 * 64 + 232, 1024, 2048, 512), (254, 768, 8192, 256)]:
+        x = rnd((M, K), dev, 1.0, 1, BF16)
+        w = rnd((N, K), dev, 0.05, 2, BF16)
+        bias = rnd((N,), dev, 0.5, 3)
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out, colscale=cs, colscale_cols=cols)
+        ref = x.float() @ w.float().t() + bias.to(BF16).float()
+        ref[:, :cols] *= cs
+        close(out, ref, 1e-2, 2e-2, f'colscale {M}x{N}x{K}')
+        plain = torch.empty_like(out)
+        ops.linear_fwd(x, w, bias, plain)
+        assert torch.equal(out[:, cols:], plain[:, cols:])                 # the other columns are untouched, bit for bit
+    with pytest.raises(hip.HipLibraryError):
+        ops.linear_fwd(x, w, bias, torch.empty(M, N, device=dev), ops.EPI_F32_RESID, resid=torch.empty(M, N, device=dev), colscale=cs, colscale_cols=64)
+
+
 # ------------------------------------------------------------------------------------------- attention backward, single-pass form
 @pytest.mark.parametrize('B,H,Nq,Nk', [(1, 2, 300, 700), (2, 1, 64, 512), (1, 2, 100, 45), (1, 2, 1023, 1300)])
 def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
