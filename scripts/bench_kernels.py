@@ -89,6 +89,14 @@ if __name__ == '__main__':
         ms = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, H, 0.125, False))
         fl = 4.0 * N * N * D * B
         print(f'attn fwd  {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s (algorithmic)')
+        qp = (q.float() * (0.125 * ops.LOG2E)).to(BF16)
+        for rep in range(2):
+            ms = timeit(lambda: ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True))
+            print(f'attn fwd, prescaled q  {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s (algorithmic)')
+            ms = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, H, 0.125, False))
+            print(f'attn fwd               {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s (algorithmic)')
+        ms = timeit(lambda: ops.attn_bwd(qp, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2*D], dqkv[:, :, 2*D:], H, 0.125, False, q_prescaled=True))
+        print(f'attn bwd, prescaled q  {ms:7.3f} ms')
         ms = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2*D], dqkv[:, :, 2*D:], H, 0.125, False))
         print(f'attn bwd  {ms:7.3f} ms {2*fl/ms/1e9:7.1f} TF/s (algorithmic 2x fwd; executed 3.5x)')
         bwd = lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2*D], dqkv[:, :, 2*D:], H, 0.125, False)
