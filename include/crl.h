@@ -55,6 +55,9 @@ size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t
  * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent
  * workgroups per CU: epilogues overlap main loops) for the NT / NN layouts whenever legal. */
 int crl_gemm_set_policy(int policy);
+/* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
+   < 0 = never cut.  Process-wide. */
+int crl_gemm_set_quant_cost(float c);
 /* Data-parallel runs share the GPU with RCCL's all-reduce kernels (ref: DistributedDataParallel's bucket all-reduces,
  * task/task_cruller_pretrain.py:181-189, overlapping backward).  The 256-row kernels are persistent: one (two) resident
  * workgroup(s) per CU.

@@ -273,24 +273,34 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
   return p;
 }
 
-// Wave quantisation: the 256x256 kernel runs one workgroup per CU, so R*ntn tiles cost ceil(R*ntn/256) full tile times.  When
-// trimming a few row tiles lands on a whole number of waves, the big kernel takes the first 256*R rows and the remaining rows
-// (< 9 row tiles) go to the 128x128 kernel, whose small tiles pack 2 per CU.  Returns R, or -1 for "no split".
-static int64_t quant_rows(int layout, int64_t M, int64_t N) {
+// Wave quantisation: the 256x256 kernel runs one workgroup per CU, so R*ntn tiles cost about ceil(R*ntn/256) tile times.  When trimming
+// a few row tiles lands on a whole number of rounds, the big kernel takes the first 256*R rows and the remaining rows go to the 128x128
+// kernel (its contraction cut into slabs when it is long: rem_split).  Whether that pays depends on the contraction: the cut costs a
+// second launch + the small kernel (~25-35 us whatever K is, thanks to the slabs), and saves one round of 256x256 tiles (~27 us at K = 1024,
+// ~95 us at K = 4096).  Measured on the cfg-3 encoder shapes (scripts/bench_kernels.py quant, round 3): K = 1024 never pays (qkv 265 uncut
+// vs 286 us cut, fc1+GELU 457 vs 470), out-width 1024 with K >= 2048 always does (fc1 dgrad 378 -> 319 us, qkv dgrad 289 -> 255, fc2 403 ->
+// 349, kv dgrad 204 -> 185); cutting MORE than the last partial round (the round-2 model priced a round of small tiles at 0.32 of a
+// big one; it is 0.75) never does.  Returns R, or -1 for "no cut".
+static float g_quant_cost = 1.0f;   // multiplies the modelled cost of the remainder launch; < 0: never cut (tuning aid)
+extern "C" int crl_gemm_set_quant_cost(float c) { g_quant_cost = c; return 0; }
+static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap);
+static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
+  if (layout == CRL_TN || g_quant_cost < 0.f) return -1;
   const int64_t ntn = (N + 255) / 256, rmax = M / 256, ncu = crl_gemm_cus();
-  const int64_t wmax = (((M + 255) / 256) * ntn + ncu - 1) / ncu;   // whole tile times of the unsplit launch
+  const int64_t wmax = (((M + 255) / 256) * ntn + ncu - 1) / ncu;   // rounds of the uncut launch
+  auto round_us = [](double k) { return 5.0 + 22.0 * k / 1024.0; }; // one round of 256x256 tiles (plain epilogue, sustained clock)
+  // uncut: the tiles of the last partial round start while the stragglers of the round before still run (dynamic schedule)
+  double best_cost = ((double)wmax - 0.2) * round_us((double)K);
   int64_t best_r = -1;
-  double best_cost = (double)wmax;                                    // in units of one 256-tile time
-  if (layout == CRL_TN) return -1;
-  // candidates: the most row tiles that fit w whole rounds of the resident workgroups (with reserved CUs a round is shorter, so the
-  // cut moves: 49 512 x 1024 on 224 CUs = 168 row tiles in 3 rounds + 25.4 row tiles for the small kernel)
   for (int64_t w = wmax; w >= 1 && w >= wmax - 2; --w) {
     const int64_t r = (w * ncu) / ntn < rmax ? (w * ncu) / ntn : rmax;
     const int64_t rem = M - 256 * r;
     if (r < 1 || rem <= 0) continue;
-    const double small = 0.32 * (double)((((rem + 127) / 128) * ((N + 127) / 128) + 2 * ncu - 1) / (2 * ncu));
-    const double cost = (double)((r * ntn + ncu - 1) / ncu) + small;
-    if (cost < best_cost - 0.2) { best_cost = cost; best_r = r; }
+    const int ns = rem_split(epilogue, rem, N, K, 8);
+    const int64_t t128 = ((rem + 127) / 128) * ((N + 127) / 128) * ns, full = t128 / (2 * ncu), part = t128 - full * 2 * ncu;
+    const double small = 14.0 + (ns > 1 ? 8.0 : 0.0) + round_us((double)K / ns) * (0.75 * (double)full + (part == 0 ? 0.0 : part <= ncu ? 0.5 : 0.75));
+    const double cost = (double)((r * ntn + ncu - 1) / ncu) * round_us((double)K) + (double)g_quant_cost * small;
+    if (cost < best_cost - 3.0) { best_cost = cost; best_r = r; }
   }
   return best_r;
 }
@@ -300,7 +310,7 @@ static int64_t quant_rows(int layout, int64_t M, int64_t N) {
 #ifndef G_REM_SPLIT
 #define G_REM_SPLIT 1
 #endif
-static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap = 8) {
+static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
   if (!G_REM_SPLIT || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
   const int64_t nk = K / 64, tiles = ((rem + 127) / 128) * ((N + 127) / 128);
   if (nk < 32 || tiles >= 128) return 1;
@@ -331,9 +341,9 @@ extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t
     if (ns > 1) return (size_t)ns * M * N * sizeof(float);
   }
   if (p.big && g_policy != 3) {
-    const int64_t r = quant_rows(layout, M, N);
+    const int64_t r = quant_rows(layout, epilogue, M, N, K);
     if (r > 0) {
-      const int ns = rem_split(epilogue, M - 256 * r, N, K);
+      const int ns = rem_split(epilogue, M - 256 * r, N, K, 8);
       if (ns > 1) return (size_t)ns * (M - 256 * r) * N * sizeof(float);
     }
   }
@@ -409,7 +419,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     return 0;
   }
   if (p.big) {
-    const int64_t best_r = quant_rows(layout, M, N);
+    const int64_t best_r = quant_rows(layout, epilogue, M, N, K);
     if (best_r < 0) return crl_gemm256_launch(layout, epilogue, a, 1, s);
     const int64_t m1 = 256 * best_r;
     GemmArgs big = a;
@@ -426,7 +436,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     rest.ntm = (int)((M - m1 + BM - 1) / BM); rest.ntn = (int)((N + BN - 1) / BN);
     rest.kchunk = (int)((K + 63) / 64);
     const int64_t rem = M - m1;
-    const int ns = rem_split(epilogue, rem, N, K);
+    const int ns = rem_split(epilogue, rem, N, K, 8);
     if (ns > 1 && ws && ws_bytes >= (size_t)ns * rem * N * sizeof(float)) {
       GemmArgs sl = rest;
       sl.bias = nullptr; sl.aux = nullptr; sl.resid = nullptr;

@@ -24,6 +24,7 @@ SIGNATURES = {
     'crl_last_error': (c_char_p, []),
     'crl_gemm_ws_bytes': (Z, [I, I, L, L, L]),
     'crl_gemm_set_policy': (I, [I]),
+    'crl_gemm_set_quant_cost': (I, [F]),
     'crl_gemm_set_schedule': (I, [I]),
     'crl_gemm_set_reserved_cus': (I, [I]),
     'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, F, L, P, Z, P]),

@@ -53,6 +53,23 @@ if __name__ == '__main__':
                 gemm_case('lm head', 'NT', 8184, 50304, 1024, policy=pol)
                 gemm_case('square 8192', 'NT', 8192, 8192, 8192, policy=pol)
         sys.exit(0)
+    if which == 'quant':    # the wave-quantisation cut at several cost constants, encoder step shapes, interleaved
+        M = 49512
+        for rep in range(2):
+            for c in (1.0, 0.0, -1.0):      # the model, always cut the last partial round, never cut
+                hip.call('crl_gemm_set_quant_cost', c)
+                print(f'--- quant cost {c}')
+                gemm_case('qkv', 'NT', M, 3072, 1024)
+                gemm_case('proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID)
+                gemm_case('fc1 gelu', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU)
+                gemm_case('fc2 resid', 'NT', M, 1024, 4096, ops.EPI_F32_RESID)
+                gemm_case('dec kv', 'NT', M, 2048, 1024)
+                gemm_case('dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU)
+                gemm_case('dgrad fc1', 'NN', M, 4096, 1024)
+                gemm_case('dgrad qkv', 'NN', M, 3072, 1024)
+                gemm_case('dgrad proj', 'NN', M, 1024, 1024)
+                gemm_case('dgrad dec kv', 'NN', M, 2048, 1024)
+        sys.exit(0)
     if which == 'gemm':
         for pol in (2, 1):
             gemm_case('square 8192', 'NT', 8192, 8192, 8192, policy=pol)

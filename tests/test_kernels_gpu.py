@@ -373,9 +373,20 @@ def test_gemm_dynamic_tile_schedule(dev):
 
 
 def test_gemm_wave_quantisation_split(dev):
-    """auto policy, 17 x 16 tiles of 256: the big kernel takes 16 row tiles (one full wave), the 128 kernel the last 104 rows"""
-    from pixparse_amd import ops
+    """auto policy, 17 x 16 tiles of 256: the big kernel takes 16 row tiles (one full wave), the 128 kernel the last 104 rows (with so short
+    a contraction the cost model would not cut: its remainder cost is zeroed for the test)"""
+    from pixparse_amd import hip, ops
     M, N, K = 256 * 16 + 104, 4096, 128
+    hip.call('crl_gemm_set_quant_cost', 0.0)
+    try:
+        _quant_split_case(dev, M, N, K)
+    finally:
+        hip.call('crl_gemm_set_quant_cost', 1.0)
+    _quant_split_case(dev, M, N, K)          # and uncut (ragged last row tile inside the 256 kernel)
+
+
+def _quant_split_case(dev, M, N, K):
+    from pixparse_amd import ops
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
