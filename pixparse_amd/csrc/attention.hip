@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 
 // ======================================================================================= dK, dV
 // workgroup = 128 keys of one (b,h) (32 per wave, K/V fragments in registers), sweeps query tiles of 64.
-template <bool CAUSAL, bool DROP = false>
+// PRE: q carries scale * log2(e) (crl_attn_bwd q_prescaled): the logits come out of the MFMAs in base 2 and the multiply by c = 1 goes
+template <bool CAUSAL, bool DROP = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   constexpr int BUF = 2 * 8192 + 512;  // [Q | dO | lse(64 f32) | delta(64 f32)]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[r] * c);
+          const float p = __builtin_amdgcn_exp2f(PRE ? s[r] : s[r] * c);
           s[r] = p;
           dp[r] = p * dp[r];
         }
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
 
 // ======================================================================================= dQ
 // workgroup = 128 queries (32 per wave, Q/dO fragments in registers), sweeps key tiles of 64.
-template <bool CAUSAL, bool DROP = false>
+template <bool CAUSAL, bool DROP = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c) * dp[r];
+        for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(PRE ? s[r] : s[r] * c) * dp[r];
       }
       __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
@@ -1135,6 +1136,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     if (g_bwd_parts & 2) {
       CRL_PROF_START(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream, 6.0 * 64 * pairs * B * H);
       if (drop) { if (causal) attn_bwd_dkdv_kernel<true, true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false, true><<<gk, 256, 0, s>>>(a); }
+      else if (q_prescaled) { if (causal) attn_bwd_dkdv_kernel<true, false, true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false, false, true><<<gk, 256, 0, s>>>(a); }
       else if (causal) attn_bwd_dkdv_kernel<true><<<gk, 256, 0, s>>>(a); else attn_bwd_dkdv_kernel<false><<<gk, 256, 0, s>>>(a);
       CRL_PROF_STOP(CRL_K_ATTN_BWD_DKDV + (causal ? 1 : 0), stream);
     }
@@ -1145,6 +1147,7 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     if (g_bwd_parts & 4) {
       CRL_PROF_START(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream, 2.0 * 64 * pairs * B * H);
       if (drop) { if (causal) attn_bwd_dq_kernel<true, true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false, true><<<gq, 256, 0, s>>>(a); }
+      else if (q_prescaled) { if (causal) attn_bwd_dq_kernel<true, false, true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false, false, true><<<gq, 256, 0, s>>>(a); }
       else if (causal) attn_bwd_dq_kernel<true><<<gq, 256, 0, s>>>(a); else attn_bwd_dq_kernel<false><<<gq, 256, 0, s>>>(a);
       CRL_PROF_STOP(CRL_K_ATTN_BWD_DQ + (causal ? 1 : 0), stream);
     }

@@ -38,7 +38,9 @@ def short(name):
         elif ch == '(' and depth == 0:
             break
         out += ch
-    return out.strip()
+    out = out.strip()
+    m = re.match(r'^(attn_\w+)<(\w+)(?:,[^>]*)?>$', out)      # attention kernels: <causal, dropout, prescaled-q> -> <causal> (bench.py's names)
+    return f'{m.group(1)}<{m.group(2)}>' if m else out
 
 
 # kernels whose grid does not tell their launch shapes apart, and the kernel launched right before them in the same crl_* call whose
