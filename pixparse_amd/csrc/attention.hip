@@ -518,8 +518,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
       __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+#ifdef ATT_TIMING_HALF_LDS_BWD   // timing-only (wrong results): half of the LDS fragment reads -- how LDS-read-bound is the dK/dV pass?
+        const bf16x8 fr = frag_row(ql, la, 32 * qb, ks);
+        s = mfma32(fr, kf[ks], s);
+        dp = mfma32(fr, vf[ks], dp);
+#else
         s = mfma32(frag_row(ql, la, 32 * qb, ks), kf[ks], s);
         dp = mfma32(frag_row(dol, la, 32 * qb, ks), vf[ks], dp);
+#endif
       }
       __builtin_amdgcn_s_setprio(0);
       const int qbase = t * 64 + 32 * qb;
@@ -552,10 +558,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnArgs a)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 pf = acc_frag(s, ss), dsf = acc_frag(dp, ss);
+#ifdef ATT_TIMING_HALF_LDS_BWD
+        const bf16x8 t0 = frag_tr(dol, la, 32 * qb + 16 * ss, 0), t1 = frag_tr(dol, la, 32 * qb + 16 * ss, 1);
+        dv0 = mfma32(t0, pf, dv0);
+        dv1 = mfma32(t1, pf, dv1);
+        dk0 = mfma32(t0, dsf, dk0);
+        dk1 = mfma32(t1, dsf, dk1);
+#else
         dv0 = mfma32(frag_tr(dol, la, 32 * qb + 16 * ss, 0), pf, dv0);
         dv1 = mfma32(frag_tr(dol, la, 32 * qb + 16 * ss, 1), pf, dv1);
         dk0 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 0), dsf, dk0);
         dk1 = mfma32(frag_tr(ql, la, 32 * qb + 16 * ss, 1), dsf, dk1);
+#endif
       }
       __builtin_amdgcn_s_setprio(0);
     }
