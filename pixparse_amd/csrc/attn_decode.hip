@@ -1,9 +1,9 @@
 // Single-query attention for generation with a KV cache (include/crl.h: crl_attn_decode), head_dim 64.
 // One new token per sequence attends to Nk cached keys: 256 B of K/V per key and 256 FLOP -- purely HBM-bound, no
 // matrix cores. The key range of every (batch, head) is split over `nsplit` workgroups so that a handful of sequences
-// still covers the chip ("flash decoding"); a lane owns a key: it reads that key's 128-B K row, takes the dot product
-// with the query (held in registers by every lane), keeps a private online-softmax state and a private fp32 P.V
-// accumulator over the keys it visits. Lanes, then waves, then splits are merged by rescaling with 2^(m - m_max) in a
+// still covers the chip ("flash decoding"); eight lanes own a key (16 bytes of its K and V rows each: whole rows per load
+// instruction), take partial dot products with their 8 query channels, sum them over the 8 lanes, keep the online-softmax state
+// of their key group and a private fp32 P.V accumulator of their 8 channels. Key groups, waves, then splits are merged by rescaling with 2^(m - m_max) in a
 // fixed order (deterministic); a key range of up to 1024 keys (the decoder's self-attention cache) is one workgroup per
 // (b, h) that normalises and stores directly. P is rounded to bf16 before P.V like crl_attn_fwd, the row sum stays fp32.
 #include "common.h"
@@ -30,71 +30,88 @@ __device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+// sum over the 8 lanes that share a key (lane & 7 = which 16-byte part of the row): two quad permutes and a half-row mirror, on the VALU's
+// DPP path (no LDS crossbar)
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  return v;
+}
+
+// Eight lanes share a key: lane & 7 owns 16 bytes (8 channels) of its 128-byte K and V rows, lane >> 3 picks the key among the 8 a
+// load instruction covers, so every load of a wave fetches 8 whole rows (round 3: the lane-per-key form issued 64 different 128-byte
+// lines per instruction and re-fetched each of them 8 times through a 32 KiB L1 that cannot hold a wave's 16 KiB x 12 waves: 3.0 TB/s).
+// All 16 loads of a 64-key batch are in flight before the first use.  The score is a partial dot product over the lane's 8 channels
+// summed over the 8 lanes; the online-softmax state (m, l) is replicated in the 8 lanes of a key group and each lane accumulates its
+// own 8 output channels.
 __global__ __launch_bounds__(256) void attn_decode_kernel(const DecArgs a) {
   __shared__ float red[4][66];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane & 7, kg = lane >> 3;
   const int bh = blockIdx.x, split = blockIdx.y;
   const int b = bh / a.H, h = bh % a.H;
   const int nk = a.nk_m1 ? min(a.Nk, *a.nk_m1 + 1) : a.Nk;
   const int k_lo = split * a.chunk, k_hi = min(nk, k_lo + a.chunk);
   const float c = a.scale * LOG2E_D;
 
-  float q[64];
+  float q[8];
   {
-    const uint4* qp = reinterpret_cast<const uint4*>(a.q + (a.q_row ? (int64_t)(*a.q_row) * a.q_row_stride : 0) + b * a.q_bs + h * 64);
+    const uint4 qv = *reinterpret_cast<const uint4*>(a.q + (a.q_row ? (int64_t)(*a.q_row) * a.q_row_stride : 0) + b * a.q_bs + h * 64 + 8 * part);
+    unpack8(qv, q);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f[8];
-      unpack8(qp[j], f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q[8 * j + e] = f[e] * c;     // scores directly in the log2 domain
-    }
+    for (int e = 0; e < 8; ++e) q[e] *= c;                       // scores directly in the log2 domain
   }
-  float m = -INFINITY, l = 0.f, acc[64];
+  float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
-  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const u16* kb = a.k + b * a.k_bs + h * 64 + 8 * part;
+  const u16* vb = a.v + b * a.v_bs + h * 64 + 8 * part;
 
-  for (int key = k_lo + wave * 64 + lane; key < k_hi; key += 256) {
-    const uint4* kp = reinterpret_cast<const uint4*>(a.k + b * a.k_bs + (int64_t)key * a.k_rs + h * 64);
-    const uint4* vp = reinterpret_cast<const uint4*>(a.v + b * a.v_bs + (int64_t)key * a.v_rs + h * 64);
+  for (int base = k_lo + wave * 64; base < k_hi; base += 256) {
     uint4 kr[8], vr[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kr[j] = kp[j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vr[j] = vp[j];
-    float s0 = 0.f, s1 = 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int key = min(base + 8 * j + kg, k_hi - 1);          // clamped: rows past the range are loaded twice and skipped below
+      kr[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * a.k_rs);
+      vr[j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * a.v_rs);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f[8];
       unpack8(kr[j], f);
+      float s0 = f[0] * q[0], s1 = f[1] * q[1];
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) { s0 = __builtin_fmaf(f[e], q[8 * j + e], s0); s1 = __builtin_fmaf(f[e + 1], q[8 * j + e + 1], s1); }
-    }
-    const float s = s0 + s1;
-    const float m_new = fmaxf(m, s);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);        // first key: exp2(-inf) = 0
-    const float p = __builtin_amdgcn_exp2f(s - m_new);
-    const float pb = round_bf(p);
-    l = l * alpha + p;
-    m = m_new;
+      for (int e = 2; e < 8; e += 2) { s0 = __builtin_fmaf(f[e], q[e], s0); s1 = __builtin_fmaf(f[e + 1], q[e + 1], s1); }
+      const float s = sum8(s0 + s1);
+      if (base + 8 * j + kg < k_hi) {                            // uniform over the 8 lanes of a key
+        const float m_new = fmaxf(m, s);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // first key: exp2(-inf) = 0
+        const float p = __builtin_amdgcn_exp2f(s - m_new);
+        const float pb = round_bf(p);
+        l = l * alpha + p;
+        m = m_new;
+        unpack8(vr[j], f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f[8];
-      unpack8(vr[j], f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[8 * j + e] = __builtin_fmaf(acc[8 * j + e], alpha, pb * f[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(acc[e], alpha, pb * f[e]);
+      }
     }
   }
-  // lanes -> wave
+  // key groups -> wave: the 8 groups of a wave hold different references
   const float m_w = wave_max(m);
   const float r = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_w);
-  const float l_w = wave_sum(l * r);
+  float l_w = l * r;
+  l_w += __shfl_xor(l_w, 8, 64); l_w += __shfl_xor(l_w, 16, 64); l_w += __shfl_xor(l_w, 32, 64);
 #pragma unroll
-  for (int d = 0; d < 64; ++d) acc[d] = wave_sum(acc[d] * r);
-  if (lane == 0) {
-    red[wave][0] = m_w; red[wave][1] = l_w;
+  for (int e = 0; e < 8; ++e) {
+    float v = acc[e] * r;
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    acc[e] = v;
+  }
+  if (kg == 0) {
+    if (part == 0) { red[wave][0] = m_w; red[wave][1] = l_w; }
 #pragma unroll
-    for (int d = 0; d < 64; ++d) red[wave][2 + d] = acc[d];
+    for (int e = 0; e < 8; ++e) red[wave][2 + 8 * part + e] = acc[e];
   }
   __syncthreads();
   // waves -> workgroup partial (thread d < 64 owns output channel d)
