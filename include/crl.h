@@ -100,6 +100,15 @@ int crl_attn_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, in
 int crl_linear_skinny_bf16(int epilogue, int M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
                            int64_t ldw, const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
                            const int* out_row_dev, int64_t out_row_stride, void* stream);
+/* The same with the LayerNorm in FRONT of the projection fused in (post-LN BART: hidden = LayerNorm(residual sum); the next
+ * projection reads bf16(hidden), the next residual add reads hidden):  h = LayerNorm(x_f32[M, K]; gamma, beta, eps) with the arithmetic of
+ * crl_layernorm_fwd (bit-identical), out = epilogue(bf16(h) @ W^T + bias); h_f32 (optional, needs N >= K) receives the fp32 h.
+ * Every workgroup normalises the <= 16 rows for itself (L2 reads) -- one launch per LayerNorm less on the decode step's dependent chain.
+ * 64 <= K <= 2048; epilogue CRL_EPI_BF16 or CRL_EPI_BF16_GELU. */
+int crl_linear_skinny_ln_bf16(int epilogue, int M, int64_t N, int64_t K, const float* x_f32, int64_t ldx, const float* gamma,
+                              const float* beta, float eps, float* h_f32, int64_t ldh, const void* W, int64_t ldw,
+                              const float* bias, void* out, int64_t ldo, const int* out_row_dev, int64_t out_row_stride,
+                              void* stream);
 
 /* column sums of a bf16 matrix into fp32 (bias gradients): out[n] (+)= sum_m X[m,n].
  * ws: >= crl_colsum_ws_bytes(N) bytes of scratch. */

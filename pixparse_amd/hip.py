@@ -31,6 +31,7 @@ SIGNATURES = {
     'crl_attn_decode_ws_bytes': (Z, [I, I, I]),
     'crl_attn_decode': (I, [P, L, P, L, L, P, L, L, P, L, I, I, I, F, P, P, L, P, Z, P]),
     'crl_linear_skinny_bf16': (I, [I, I, L, L, P, L, P, L, P, P, L, P, L, P, L, P]),
+    'crl_linear_skinny_ln_bf16': (I, [I, I, L, L, P, L, P, P, F, P, L, P, L, P, P, L, P, L, P]),
     'crl_colsum_ws_bytes': (Z, [L]),
     'crl_colsum_bf16': (I, [P, L, L, L, P, I, P, P]),
     'crl_layernorm_fwd': (I, [P, P, P, F, L, L, P, P, P, P, P]),

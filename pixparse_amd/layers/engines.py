@@ -15,11 +15,16 @@ Arithmetic restated (reference call sites):
 """
 from typing import Callable, Dict, Optional, Tuple
 
+import os
+
 import torch
 
 from .. import ops
 from ..ops import BF16, F32, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC
 from .arena import ParamArena
+
+
+_DECODE_LN_FUSION = os.environ.get('PIXPARSE_AMD_DECODE_LN_FUSION', '1') != '0'     # A/B switch of the generation step (scripts/bench_generate.py)
 
 
 class Buffers:
@@ -574,6 +579,21 @@ class BartEngine(_Base):
             aux = self.buf('gen.gelu_pre', out.shape, BF16) if epi == EPI_BF16_GELU else None   # the GEMM epilogue also stores the pre-activation
             ops.linear_fwd(x, w, b, out, epi, aux=aux, resid=resid)
 
+    def _ln_lin(self, ln_name, t32, key, eps, w, b, out, epi=ops.EPI_BF16, **row):
+        """h = LayerNorm(t32), out = epilogue(bf16(h) @ w^T + b); returns the fp32 h (the next residual).  Decode rows: ONE launch
+        (crl_linear_skinny_ln_bf16, every workgroup normalises the <= 16 rows for itself); more rows: ln_fwd + the GEMM"""
+        if t32.shape[0] <= ops.SKINNY_MAX_ROWS and w.shape[0] >= t32.shape[1] and _DECODE_LN_FUSION:
+            h = self.buf(key + '.y32', tuple(t32.shape), F32)
+            ops.linear_skinny_ln(t32, self.P(ln_name + '.weight'), self.P(ln_name + '.bias'), eps, h, w, b, out, epi, **row)
+            return h
+        h, hb = self.ln_fwd(ln_name, t32, key, eps, True, True)
+        if row:
+            assert hb.shape[0] <= ops.SKINNY_MAX_ROWS, 'a device-selected output row needs the skinny kernel (<= 16 sequences)'
+            ops.linear_skinny(hb, w, b, out, epi, **row)
+        else:
+            self._lin(hb, w, b, out, epi)
+        return h
+
     def decode_begin(self, enc16: torch.Tensor, B: int, S: int, max_len: int):
         """enc16 bf16 [B*S, D].  Projects the encoder states to every layer's cross-attention K/V once and lays out
         empty self-attention caches [B, max_len, 3D] (q | k | v per row, read by the attention kernel as strided views).
@@ -649,32 +669,34 @@ class BartEngine(_Base):
         scale = (D // H) ** -0.5
         emb = self.buf('gen.emb', (B, D), F32)
         ops.embed_decode(ids, self.P(dp + 'embed_tokens.weight'), self.P(dp + 'embed_positions.weight'), emb, step, 2)
-        h, hb = self.ln_fwd(dp + 'layernorm_embedding', emb, 'gen.ln_emb', eps, want_f32=True, want_bf16=True)
+        # post-LN BART: every LayerNorm feeds exactly one projection (bf16) and one residual add (fp32), so it rides in FRONT of that
+        # projection's launch (crl_linear_skinny_ln_bf16) -- 3 launches per layer less on the dependent chain of the step
+        t_in, ln_in, ln_key = emb, dp + 'layernorm_embedding', 'gen.ln_emb'
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'gen.l{i}'
             kvc = self.bufs.t[self.tag + '.' + k + '.kvc']
             # q | k | v of this token in ONE projection, straight into cache row `step`; the attention takes q from that row
-            ops.linear_skinny(hb, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3), kvc[:, 0, :],
-                              out_row=step, out_row_stride=3 * D)
+            h = self._ln_lin(ln_in, t_in, ln_key, eps, self.fw('w', lp, 'self_attn', 'q_proj', 3), self.fb('p', lp, 'self_attn', 'q_proj', 3),
+                             kvc[:, 0, :], out_row=step, out_row_stride=3 * D)
             o1 = self.buf(k + '.o1', (B, D), BF16)
             ops.attn_decode(kvc[:, 0, 0:D], kvc[:, :, D:2 * D], kvc[:, :, 2 * D:], o1, H, scale, nk_minus1=step,
                             q_row=step, q_row_stride=3 * D)
             t1 = self.buf(k + '.t1', (B, D), F32)
             self._lin(o1, self.W(lp + 'self_attn.out_proj.weight'), self.P(lp + 'self_attn.out_proj.bias'), t1, EPI_F32_RESID, resid=h)
-            h1, h1b = self.ln_fwd(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, True, True)
             q2 = self.buf(k + '.q2', (B, D), BF16)
-            self._lin(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2)
+            h1 = self._ln_lin(lp + 'self_attn_layer_norm', t1, k + '.ln1', eps, self.W(lp + 'encoder_attn.q_proj.weight'),
+                              self.P(lp + 'encoder_attn.q_proj.bias'), q2)
             kv3 = self.bufs.t[self.tag + '.' + k + '.kv2'].view(B, S, 2 * D)
             o2 = self.buf(k + '.o2', (B, D), BF16)
             ops.attn_decode(q2, kv3[:, :, 0:D], kv3[:, :, D:], o2, H, scale)
             t2 = self.buf(k + '.t2', (B, D), F32)
             self._lin(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, EPI_F32_RESID, resid=h1)
-            h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
             act = self.buf(k + '.act', (B, F_), BF16)
-            self._lin(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU)
+            h2 = self._ln_lin(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU)
             t3 = self.buf(k + '.t3', (B, D), F32)
             self._lin(act, self.W(lp + 'fc2.weight'), self.P(lp + 'fc2.bias'), t3, EPI_F32_RESID, resid=h2)
-            h, hb = self.ln_fwd(lp + 'final_layer_norm', t3, k + '.ln3', eps, True, True)
+            t_in, ln_in, ln_key = t3, lp + 'final_layer_norm', k + '.ln3'
+        _, hb = self.ln_fwd(ln_in, t_in, ln_key, eps, False, True)      # the LM head has 3144 workgroups: its LayerNorm stays a launch of its own
         logits = self.buf('gen.logits', (B, self.Vp), BF16)
         self._lin(hb, self.arena.shadow(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D), None, logits)
         step.add_(1)

@@ -68,6 +68,17 @@ def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
              _p(resid), resid.stride(0) if resid is not None else 0, _p(out_row), int(out_row_stride), _stream())
 
 
+def linear_skinny_ln(x32: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, h32: Optional[torch.Tensor], w: torch.Tensor,
+                     bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16, n: Optional[int] = None,
+                     out_row: Optional[torch.Tensor] = None, out_row_stride: int = 0) -> None:
+    """out = epilogue(bf16(LayerNorm(x32)) @ w^T + bias) for M <= 16 rows, h32 (optional) = the fp32 LayerNorm output
+    (crl_linear_skinny_ln_bf16: the LayerNorm in front of a decode-step projection without a launch of its own)"""
+    M, K = x32.shape
+    N = n if n is not None else w.shape[0]
+    hip.call('crl_linear_skinny_ln_bf16', epi, M, N, K, _p(x32), x32.stride(0), _p(gamma), _p(beta), float(eps), _p(h32),
+             h32.stride(0) if h32 is not None else 0, _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), _p(out_row), int(out_row_stride), _stream())
+
+
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epi: int = EPI_BF16,
                  aux: Optional[torch.Tensor] = None, k: Optional[int] = None) -> None:
     """out[M, Kin] = dy[M, N] @ w[N, Kin]; contraction over N (= dy.shape[1])."""

@@ -210,6 +210,40 @@ def test_linear_skinny_vs_gemm_semantics(dev, M, N, K):
         close(out, g, 8e-3, 8e-3, 'skinny vs gemm')
 
 
+@pytest.mark.parametrize('M,N,K', [(8, 3072, 1024), (1, 1024, 1024), (16, 4096, 768), (5, 784, 256)])
+def test_linear_skinny_with_layernorm_in_front(dev, M, N, K):
+    """crl_linear_skinny_ln_bf16 == crl_layernorm_fwd followed by crl_linear_skinny_bf16, bit for bit (projection output, GELU variant,
+    device-selected output row, fp32 LayerNorm output), and both against fp32 torch"""
+    from pixparse_amd import hip, ops
+    t = rnd((M, K), dev, 2.0, 1) + 0.5
+    gamma, beta = 1.0 + rnd((K,), dev, 0.2, 2), rnd((K,), dev, 0.3, 3)
+    w = rnd((N, K), dev, 0.1, 4, BF16)
+    bias = rnd((N,), dev, 0.5, 5)
+    y32, y16 = torch.empty(M, K, device=dev), torch.empty(M, K, dtype=BF16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(t, gamma, beta, 1e-5, y32, y16, mean, rstd)
+    for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU):
+        want = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_skinny(y16, w, bias, want, epi)
+        got = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
+        h = torch.full((M, K), float('nan'), device=dev)
+        ops.linear_skinny_ln(t, gamma, beta, 1e-5, h if N >= K else None, w, bias, got, epi)
+        assert torch.equal(got, want), f'epi {epi}: {float((got.float() - want.float()).abs().max())}'
+        if N >= K:
+            assert torch.equal(h, y32)
+    ref = torch.nn.functional.layer_norm(t, (K,), gamma, beta, 1e-5).to(BF16).float() @ w.float().t() + bias.to(BF16).float()
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_skinny_ln(t, gamma, beta, 1e-5, None, w, bias, out)
+    close(out, ref, 2e-2, 2e-2, 'skinny + LN vs torch')
+    big = torch.zeros(M, 3, N, dtype=BF16, device=dev)
+    row = torch.tensor([2], dtype=torch.int32, device=dev)
+    ops.linear_skinny_ln(t, gamma, beta, 1e-5, None, w, bias, big[:, 0, :], out_row=row, out_row_stride=N)
+    assert torch.equal(big[:, 2, :], out) and float(big[:, :2, :].abs().max()) == 0
+    if N < K:
+        with pytest.raises(hip.HipLibraryError):
+            ops.linear_skinny_ln(t, gamma, beta, 1e-5, torch.empty(M, K, device=dev), w, bias, out)
+
+
 @pytest.mark.parametrize('M,N,K', [(300, 288, 192), (130, 96, 288), (1000, 544, 1024)])
 def test_gemm_nn_dgrad(dev, M, N, K):
     """dx[M, K] = dy[M, N] @ w[N, K] (+ fused GELU backward)"""
