@@ -36,6 +36,15 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+BUILD_INFO = os.path.join(CSRC, 'build_info.json')      # written next to the library; git-ignored like the .so, travels with it
+
+
+def source_digest() -> dict:
+    """sha1 of every kernel source and header the library is built from"""
+    import hashlib
+    return {f: hashlib.sha1(open(os.path.join(CSRC, f), 'rb').read()).hexdigest() for f in sorted(SOURCES + HEADERS)}
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -57,8 +66,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    linked = bool(force or jobs or _stale(LIB, objs))
+    if linked:
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    # what this call did, and the sources the library now corresponds to: hip.load() refuses a library whose sources have changed since
+    import json
+    import time
+    compiled = [os.path.basename(c[-3]) for c in jobs]
+    info = dict(time=time.strftime('%Y-%m-%d %H:%M:%S'), hipcc=hipcc, flags=FLAGS, extra_flags=EXTRA_FLAGS,
+                compiled=compiled, reused=[s for s in SOURCES if s not in compiled], linked=linked, sources=source_digest())
+    with open(BUILD_INFO, 'w') as f:
+        json.dump(info, f, indent=1)
+    if verbose:
+        print(f'[build] compiled {len(compiled)} of {len(SOURCES)} translation units ({", ".join(compiled) or "all objects up to date"}); '
+              f'linked: {linked}', flush=True)
     return LIB
 
 

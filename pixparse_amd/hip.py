@@ -86,6 +86,23 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+def _check_not_stale(path: str) -> None:
+    """the library must have been built from the kernel sources lying next to it (build.py records their sha1 in build_info.json):
+    a stale .so would silently run last week's kernels.  scripts that rebuild objects by hand (scripts/ab_*.sh) set
+    PIXPARSE_AMD_SKIP_BUILD_CHECK=1."""
+    import json
+    from . import build as _build
+    if not os.path.exists(_build.BUILD_INFO):
+        return                                  # built by hand (explicit hipcc line): nothing recorded, nothing to compare
+    with open(_build.BUILD_INFO) as f:
+        built = json.load(f).get('sources', {})
+    now = _build.source_digest()
+    changed = sorted(k for k in now if built.get(k) != now[k])
+    if changed:
+        raise HipLibraryError(f'{path} is older than its sources ({", ".join(changed)} changed since it was built): run '
+                              '`python -m pixparse_amd.build` (or __graft_entry__.build()); set PIXPARSE_AMD_SKIP_BUILD_CHECK=1 to load it anyway')
+
+
 def load(path: str = None) -> ctypes.CDLL:
     """dlopen the library and bind every symbol crl.h declares; raises if any is missing."""
     global _lib
@@ -96,6 +113,8 @@ def load(path: str = None) -> ctypes.CDLL:
         raise HipLibraryError(
             f'{path} not found: build it with `python -m pixparse_amd.build` (hipcc --offload-arch=gfx950). '
             'pixparse_amd has no CPU or PyTorch fallback path.')
+    if path == LIB_PATH and os.environ.get('PIXPARSE_AMD_SKIP_BUILD_CHECK', '0') != '1':
+        _check_not_stale(path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:

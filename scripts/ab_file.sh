@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 # same-box A/B of the whole train step: committed (HEAD) version vs working-tree version of ONE csrc file
 #   gpurun -- 'bash scripts/ab_file.sh gemm.hip'       (run `git show HEAD:pixparse_amd/csrc/<file> > pixparse_amd/csrc/<file>.head` first: .git does not travel)
 cd "$(dirname "$0")/.."

@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of the whole train step for compile-time knobs of ONE csrc file:  ab_flags.sh attention.hip "-DFWD_OCC=4" "-DFWD_OCC=3" ...
 cd "$(dirname "$0")/.."
+export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 C=pixparse_amd/csrc
 F=$1; shift
 OBJ=$C/${F%.*}.o

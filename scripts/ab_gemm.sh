@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 # A/B of gemm256.hip compile-time knobs on ONE box
 cd "$(dirname "$0")/.."
 C=pixparse_amd/csrc

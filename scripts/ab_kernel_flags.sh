@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of the attention micro-benchmark for compile-time knobs of attention.hip:  ab_kernel_flags.sh "" "-DATT_TIMING_HALF_LDS_BWD" ...
 cd "$(dirname "$0")/.."
+export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 C=pixparse_amd/csrc
 for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize $flags -c $C/attention.hip -o $C/attention.o || exit 1

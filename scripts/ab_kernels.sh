@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 # same-box A/B of compile-time knobs of ONE csrc file on the kernel micro-benchmarks:
 #   ab_kernels.sh gemm2x.hip gemm2x "pol=3" "-DG2X_STAGGER=0" "-DG2X_STAGGER=1"
 # (file, scripts/bench_kernels.py mode, grep pattern, flag sets...)

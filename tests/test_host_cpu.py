@@ -896,3 +896,16 @@ print('OK')
     code2 = "from pixparse_amd.framework import DeviceEnv; e = DeviceEnv('cpu'); assert not e.distributed and e.world_size == 1; print('OK')"
     r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stderr[-2000:]
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """hip.load() compares the sha1 of every kernel source with what build.py recorded when it built the library: a library older than
+    its sources must fail loudly (it would run last week's kernels), with an explicit escape for the hand-built A/B scripts"""
+    from pixparse_amd import build, hip
+    if not os.path.exists(build.BUILD_INFO):
+        pytest.skip('library was not built through pixparse_amd.build')
+    hip._check_not_stale(hip.LIB_PATH)                                   # as built: fine
+    real = build.source_digest()
+    monkeypatch.setattr(build, 'source_digest', lambda: {**real, 'attention.hip': '0' * 40})
+    with pytest.raises(hip.HipLibraryError, match='attention.hip'):
+        hip._check_not_stale(hip.LIB_PATH)
