@@ -502,6 +502,15 @@ def cruller_loss(p, spec: ModelSpec, image: Tensor, text_input: Tensor, text_tar
     return loss
 
 
+def classifier_loss(p: Dict[str, Tensor], spec: 'ModelSpec', image: Tensor, label: Tensor, policy: str = 'bf16') -> Tuple[Tensor, Tensor]:
+    """the classification fine-tune's forward (ref task/task_cruller_finetune_xent.py:146-151, :237-247): nn.Sequential(image encoder,
+    GetCLSToken = x[:, 0, :], nn.Linear(features, classes)) under autocast, CrossEntropyLoss(ignore_index=-100) -> (loss, logits)"""
+    assert spec.enc_kind == 'vit', 'token 0 is a class token only for the ViT encoders'
+    feats = vit_forward(p, spec.enc_arch, image, policy, prefix='image_encoder.trunk.')[:, 0, :]
+    logits = _linear(feats, p['final_fc.weight'], p['final_fc.bias'], policy)
+    return cross_entropy(logits, label), logits
+
+
 def shift_tokens(text_input: Tensor, text_target: Tensor) -> Tuple[Tensor, Tensor]:
     """task_cruller_pretrain.py:241-242."""
     return text_input[:, :-1], text_target[:, 1:]

@@ -96,6 +96,9 @@ def _set_param(root: nn.Module, dotted: str, p: nn.Parameter, factories=None):
     mod.register_parameter(parts[-1], p)
 
 
+HEAD_PAD = 32   # classifier rows are padded to 32: the head's dgrad contracts over the class dimension (NN GEMM: K % 32 == 0)
+
+
 class Cruller(nn.Module):
     def __init__(self, cfg: ModelCfg, vocab_size: Optional[int] = None):
         super().__init__()
@@ -122,6 +125,7 @@ class Cruller(nn.Module):
         assert enc_dim == self.dec_arch['d_model'], f'encoder width {enc_dim} != decoder d_model {self.dec_arch["d_model"]}'
         self.arena: Optional[ParamArena] = None
         self._engines = None
+        self._head = None            # (num_classes, in_features) once add_classifier_head() ran (cruller_finetune_xent)
         self._build()
         self.reset_parameters()
         # pretrained=True (the reference default, image_encoder_timm.py:13-20 / text_decoder_hf.py:25-31): local weights when
@@ -140,10 +144,15 @@ class Cruller(nn.Module):
             arena.add(ENC_PREFIX + item[0], item[1])
         for item in BartEngine.param_shapes(self.dec_arch, self.n_layers, self.vocab_size, self.max_length):
             arena.add(DEC_PREFIX + item[0], item[1], item[2] if len(item) > 2 else None)
+        if self._head is not None:      # LAST in the arena: its gradients are the first the backward sweep completes
+            nc, feat = self._head
+            arena.add('final_fc.weight', (nc, feat), HEAD_PAD * feat)
+            arena.add('final_fc.bias', (nc,), HEAD_PAD)
         arena.materialize('cpu')
         self.arena = arena
         self._engines = None
         # module tree mirroring the reference checkpoint keys
+        self._modules.pop('final_fc', None)
         self._modules.pop('image_encoder', None)
         self._modules.pop('text_decoder', None)
         self.image_encoder = _ImageEncoder(self)
@@ -193,6 +202,32 @@ class Cruller(nn.Module):
             if n > old_v:  # transformers 5 draws new rows around the old embeddings' mean; use the mean + small noise
                 mean = old[key].mean(0, keepdim=True)
                 self._pmap[key][old_v:].copy_(mean + 1e-3 * old[key].std() * torch.randn(n - old_v, mean.shape[1]))
+
+    def add_classifier_head(self, num_classes: int, in_features: Optional[int] = None, seed: Optional[int] = None):
+        """the classification fine-tune of the reference (task_cruller_finetune_xent.py:143-150): image encoder -> token 0 (GetCLSToken) ->
+        nn.Linear(in_features, num_classes).  The head joins the parameter arena behind the decoder (nn.Linear's default init), so the same
+        clip-norm / AdamW / bucketed all-reduce see it; classify_loss() / classify_backward() run encoder + head only (the decoder's
+        gradients stay zero: with weight_decay 0, AdamW leaves it untouched, like the reference's optimiser that does not own it)."""
+        if self.enc_kind != 'vit':
+            raise NotImplementedError('the reference takes token 0 of the encoder output (GetCLSToken: x[:, 0, :]), which is a class token '
+                                      'only for the ViT encoders; a Swin feature map [B, H, W, C] does not pass its CrossEntropyLoss either')
+        feat = self.enc_arch['dim']
+        if in_features is not None and in_features != feat:
+            raise ValueError(f'classifier head expects {in_features} features, the encoder produces {feat}')
+        assert 0 < num_classes <= HEAD_PAD
+        assert self.arena.p.device.type == 'cpu' and self.arena.g is None, 'add_classifier_head must precede train_setup()'
+        old = {k: v.detach().clone() for k, v in self._pmap.items()}
+        self._head = (int(num_classes), int(feat))
+        self._build()
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        bound = feat ** -0.5                  # nn.Linear.reset_parameters: kaiming_uniform(a = sqrt 5) = U(-1/sqrt(in), 1/sqrt(in)) for both
+        with torch.no_grad():
+            for k, p in self._pmap.items():
+                if k in old:
+                    p.copy_(old[k])
+                else:
+                    p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1) * bound)
+        return self
 
     # ------------------------------------------------------------------ device placement
     def _apply(self, fn, recurse=True):
@@ -404,6 +439,49 @@ class Cruller(nn.Module):
         dec.drop = None       # the mask belongs to this forward_loss() / backward() pair only
         if self.enc_kind == 'swin':
             enc.drop = None
+
+    # ------------------------------------------------------------------ classification head (cruller_finetune_xent)
+    def classify(self, image_input: torch.Tensor) -> torch.Tensor:
+        """logits bf16 [B, HEAD_PAD] (columns >= num_classes are padding) = final_fc(encoder(image)[:, 0, :])"""
+        assert self._head is not None, 'add_classifier_head() first'
+        enc, _, bufs = self._ensure_engines()
+        _, enc16 = self.encode(image_input)
+        B, S, feat = image_input.shape[0], enc.out_tokens(), self._head[1]
+        self._cls16 = enc16.view(B, S, feat)[:, 0, :]                    # strided rows: the GEMMs take a leading dimension
+        wb = self.arena.shadow('final_fc.weight', padded=True).view(HEAD_PAD, feat)
+        logits = bufs.get('head.logits', (B, HEAD_PAD), torch.bfloat16)
+        ops.linear_fwd(self._cls16, wb, self.arena.param('final_fc.bias', padded=True), logits)
+        return logits
+
+    def classify_loss(self, image_input, label, loss_mul: float = 1.0, grad_mul: float = 1.0, grad_mul_dev: Optional[torch.Tensor] = None):
+        """autocast(bf16){ final_fc(encoder(image)[:, 0]) } -> CrossEntropyLoss(ignore_index=-100) (ref task_cruller_finetune_xent.py:237-247);
+        leaves d(loss * grad_mul) / dlogits in the logits buffer, returns the device scalar loss"""
+        logits = self.classify(image_input)
+        _, _, bufs = self._engines
+        B = logits.shape[0]
+        self._loss = bufs.get('loss', (1,), torch.float32)
+        n_valid = bufs.get('n_valid', (1,), torch.int32)
+        row_loss = bufs.get('head.row_loss', (B,), torch.float32)
+        ops.cross_entropy(logits, label.contiguous().view(-1), self._head[0], loss_mul, grad_mul, self._loss, n_valid, row_loss, logits, grad_mul_dev)
+        return self._loss
+
+    def classify_backward(self, on_ready: Optional[Callable[[str], None]] = None):
+        """backward of the last classify_loss(): head wgrad / bias grad / dgrad, the class-token rows of d(encoder output), encoder backward"""
+        enc, _, bufs = self._ensure_engines()
+        assert self.arena.g is not None, 'call alloc_training_state() (train_setup) before backward'
+        nc, feat = self._head
+        dlogits = bufs.t['head.logits']
+        B, S = dlogits.shape[0], enc.out_tokens()
+        ops.linear_wgrad(dlogits, self._cls16, self.arena.grad('final_fc.weight', padded=True).view(HEAD_PAD, feat), True)
+        ops.colsum(dlogits, self.arena.grad('final_fc.bias', padded=True), True)
+        if on_ready is not None:
+            on_ready('final_fc.weight')
+        dcls = bufs.get('head.dcls', (B, feat), torch.bfloat16)
+        ops.linear_dgrad(dlogits, self.arena.shadow('final_fc.weight', padded=True).view(HEAD_PAD, feat), dcls)
+        denc = bufs.get('denc', (B * S, feat), torch.float32)
+        denc.zero_()                                                      # only token 0 of every image receives a gradient
+        denc.view(B, S, feat)[:, 0, :].copy_(dcls)
+        enc.backward(denc, on_ready)
 
     def activation_bytes(self) -> int:
         return 0 if self._engines is None else self._engines[2].bytes()

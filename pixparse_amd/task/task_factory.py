@@ -1,6 +1,6 @@
 """name -> (TaskCls, CfgCls) registry (ref: task/task_factory.py:44-79).  The pretrain task is the hot path; the
 fine-tune tasks reuse its step, the eval tasks (f-4) the KV-cache generation path; `donut_eval_ocr` (a
-different model family) and `cruller_finetune_xent` are not built and raise a clear error."""
+different model family) is not built and raises a clear error."""
 from ..framework import DeviceEnv, Monitor
 from .task_cruller_pretrain import TaskCrullerPretrain, TaskCrullerPretrainCfg
 from .task_cruller_eval_ocr import TaskCrullerEvalOCR, TaskCrullerEvalOCRCfg
@@ -9,7 +9,9 @@ from .task_cruller_eval_docvqa import TaskCrullerEvalCORD, TaskCrullerEvalCORDCf
 from .task_cruller_finetune import (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg, TaskCrullerFinetuneDOCVQA,
                                     TaskCrullerFinetuneDOCVQACfg, TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg)
 
-_NOT_BUILT = ('donut_eval_ocr', 'cruller_finetune_xent')
+from .task_cruller_finetune_xent import TaskCrullerFinetuneXent, TaskCrullerFinetuneXentCfg
+
+_NOT_BUILT = ('donut_eval_ocr',)
 
 
 class TaskFactory:
@@ -22,6 +24,7 @@ class TaskFactory:
         'cruller_finetune_rvlcdip': (TaskCrullerFinetuneRVLCDIP, TaskCrullerFinetuneRVLCDIPCfg),
         'cruller_finetune_cord': (TaskCrullerFinetuneCORD, TaskCrullerFinetuneCORDCfg),
         'cruller_finetune_docvqa': (TaskCrullerFinetuneDOCVQA, TaskCrullerFinetuneDOCVQACfg),
+        'cruller_finetune_xent': (TaskCrullerFinetuneXent, TaskCrullerFinetuneXentCfg),
     }
 
     @classmethod

@@ -898,6 +898,16 @@ print('OK')
     assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stderr[-2000:]
 
 
+def test_finetune_xent_is_registered_and_refuses_swin():
+    from pixparse_amd.models import Cruller, ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    from pixparse_amd.task import TaskCrullerFinetuneXent, TaskFactory
+    assert TaskFactory.TASK_CLASS_REGISTRY['cruller_finetune_xent'][0] is TaskCrullerFinetuneXent
+    m = Cruller(ModelCfg(image_encoder=ImageEncoderCfg(name='swin_tiny_patch4_window7_224', image_size=(224, 224), pretrained=False),
+                         text_decoder=TextDecoderCfg(name='facebook/bart-base', pretrained=False, num_decoder_layers=1, max_length=8)), vocab_size=300)
+    with pytest.raises(NotImplementedError, match='GetCLSToken'):
+        m.add_classifier_head(16)
+
+
 def test_stale_library_is_refused(monkeypatch):
     """hip.load() compares the sha1 of every kernel source with what build.py recorded when it built the library: a library older than
     its sources must fail loudly (it would run last week's kernels), with an explicit escape for the hand-built A/B scripts"""

@@ -38,6 +38,10 @@ def _register_test_archs():
     for reg, Rv, Rs, Rb in ((register_arch, R.VIT_ARCHS, R.SWIN_ARCHS, R.BART_ARCHS),):
         reg('vit', 'vit_test', vit_a); reg('vit', 'vit_test_clip', vit_b); reg('swin', 'swin_test', swin); reg('bart', 'bart_test', bart)
         Rv['vit_test'] = vit_a; Rv['vit_test_clip'] = vit_b; Rs['swin_test'] = swin; Rb['bart_test'] = bart
+        vit_768 = dict(vit_a, patch=16, dim=768, depth=1, heads=12)          # the width the reference's classifier head hard-codes
+        bart_768 = dict(bart, d_model=768, heads=12)
+        reg('vit', 'vit_test768', vit_768); reg('bart', 'bart_test768', bart_768)
+        Rv['vit_test768'] = vit_768; Rb['bart_test768'] = bart_768
 
 
 def _cfg(enc, img, fmt, layers, L):
@@ -134,6 +138,91 @@ def test_cruller_forward_backward_vs_oracle(dev, enc, img, fmt):
     assert worst[0][0] < 5e-2, worst[:5]
     tot = torch.sqrt(sum((op[k].grad.float() ** 2).sum() for k in params))
     assert abs(float(model.arena.g.norm()) - float(tot)) / float(tot) < 2e-2
+
+
+def test_classifier_head_forward_backward_vs_oracle(dev):
+    """cruller_finetune_xent's model: image encoder -> token 0 -> Linear -> CrossEntropyLoss (ref task_cruller_finetune_xent.py:146-151,
+    :237-247) against the oracle's autograd: logits, loss (1e-3), head and encoder gradients; the decoder receives none"""
+    from oracle import ref_cpu as R
+    from pixparse_amd.models import Cruller
+    _register_test_archs()
+    enc, img, L, layers, V, B, NC = 'vit_test', (37, 50), 24, 1, 515, 32, 16
+    torch.manual_seed(0)
+    model = Cruller(_cfg(enc, img, 'RGB', layers, L), vocab_size=V)
+    model.add_classifier_head(NC, seed=1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.bias'):
+                p.normal_(0, 0.05)
+            elif p.dim() >= 2:
+                p.mul_(3.0)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith('lm_head.weight')}
+    assert tuple(params['final_fc.weight'].shape) == (NC, 128) and tuple(params['final_fc.bias'].shape) == (NC,)
+    spec = R.ModelSpec(enc, 'bart_test', layers, L, img, 3, vocab=V)
+    g = torch.Generator().manual_seed(5)
+    image = torch.randn(B, 3, *img, generator=g)
+    label = torch.randint(0, NC, (B,), generator=g)
+    label[1] = -100                                                   # CrossEntropyLoss(ignore_index=-100)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    oloss, ologits = R.classifier_loss(op, spec, image, label, 'bf16')
+    oloss.backward()
+    model.to(dev)
+    model.arena.alloc_training_state()
+    logits = model.classify(image.to(dev))
+    assert logits.shape == (B, 32) and rel(logits[:, :NC], ologits) < 2e-2
+    loss = model.classify_loss(image.to(dev), label.to(dev))
+    # the mean over 31 rows of 16 bf16 logits each (one bf16 ulp of a logit ~ 4e-3): 3e-3, not the 1e-3 of the 10^4-token LM losses
+    assert abs(float(loss) - float(oloss)) / float(oloss) < 3e-3, (float(loss), float(oloss))
+    model.classify_backward()
+    worst = sorted(((rel(model.arena.grad(k), op[k].grad), k) for k in params if op[k].grad is not None
+                    and not k.endswith('k_proj.bias') and 'attn.qkv.bias' not in k), reverse=True)
+    assert worst[0][0] < 5e-2, worst[:5]
+    for k in params:
+        if k.startswith('text_decoder.'):
+            assert op[k].grad is None and float(model.arena.grad(k).abs().max()) == 0.0, k
+    # the padded classifier rows never receive a gradient
+    assert float(model.arena.grad('final_fc.weight', padded=True)[NC * 128:].abs().max()) == 0.0
+
+
+def test_finetune_xent_task_steps(dev, tmp_path):
+    """the registry entry: checkpoint handed over as the reference's app/train.py does (task.state_dict = ...; task.resume = True), three
+    updates on dict samples, loss falls on a fixed batch, decoder untouched, checkpoint keys of the reference's nn.Sequential"""
+    from pixparse_amd.framework import DeviceEnv, Monitor
+    from pixparse_amd.models import Cruller
+    from pixparse_amd.task import TaskFactory
+    _register_test_archs()
+    from pixparse_amd.models import ImageEncoderCfg, ModelCfg, TextDecoderCfg
+    mcfg = ModelCfg(image_encoder=ImageEncoderCfg(name='vit_test768', image_fmt='RGB', image_size=(32, 48), pretrained=False),
+                    text_decoder=TextDecoderCfg(name='bart_test768', pretrained=False, num_decoder_layers=1, max_length=16))
+    from pixparse_amd.framework.config import OptimizationCfg
+    args = dict(model=mcfg, opt=OptimizationCfg(learning_rate=1e-3, warmup_learning_rate=1e-3, clip_grad_value=1.0), num_intervals=1, num_warmup_intervals=0)
+    task, cfg = TaskFactory.create_task('cruller_finetune_xent', dict(args, dtype='bfloat16'), DeviceEnv(), Monitor(output_dir=str(tmp_path)))
+    pre = Cruller(mcfg, vocab_size=task.vocab_size)
+    ckpt = {'module.' + k: v.clone() for k, v in pre.state_dict().items()}
+    task.state_dict = ckpt
+    task.resume = True
+    task.train_setup(num_batches_per_interval=8)
+    assert callable(task.state_dict)
+    for k, v in pre.state_dict().items():
+        assert torch.equal(task.model.state_dict()[k].cpu(), v), k
+    g = torch.Generator().manual_seed(0)
+    sample = {'image': torch.randn(4, 3, 32, 48, generator=g), 'label': torch.tensor([3, 0, 15, 7])}
+    dec_before = {k: v.clone() for k, v in task.model.state_dict().items() if k.startswith('text_decoder.')}
+    task.train_interval_start()
+    losses = []
+    for _ in range(4):
+        task.train_step(sample)
+        losses.append(float(task.last_loss))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert abs(losses[0] - 2.77) < 0.6                                  # ~ ln 16 at initialisation
+    for k, v in dec_before.items():
+        assert torch.equal(task.model.state_dict()[k], v), k            # zero gradients, weight decay 0: the decoder does not move
+    sd = task.state_dict()['model']
+    assert 'final_fc.weight' in sd and tuple(sd['final_fc.weight'].shape) == (16, 768) and 'encoder.trunk.cls_token' in sd
+    assert not any(k.startswith('text_decoder') for k in sd)
+    assert task.classifier(sample['image'].to(dev)).shape == (4, 16)
+    batch = task.collate_fn([{'image': torch.rand(3, 40, 40), 'label': 2}, {'image': torch.rand(3, 50, 30), 'label': 5}])
+    assert batch['image'].shape == (2, 3, 32, 48) and batch['label'].tolist() == [2, 5]
 
 
 def test_decoder_dropout_matches_oracle_with_the_same_masks(dev):
