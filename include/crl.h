@@ -285,7 +285,9 @@ int crl_grad_norm_scaled(const float* g, int64_t n, float max_norm, float grad_d
  * replayed from a hipGraph -- state[8] = learning rate of this update = timm CosineLRScheduler(t_initial, lr_min,
  * warmup_t, warmup_lr_init) at u = state[7] updates attempted so far (ref task_cruller_pretrain.py:214-224,292-295;
  * t_initial <= 0: constant base_lr), state[9] = 1 - beta1^t and state[10] = 1 / sqrt(1 - beta2^t) in double precision with
- * t = state[3] (steps actually taken, this one included), then state[7] += 1. */
+ * t = steps actually taken (this one included), then the update count advances.  The two counts are kept exactly as uint32 in words 11
+ * (steps taken, advanced by crl_grad_norm* when the step is not skipped) and 12 (updates attempted) of the state vector; state[3] and
+ * state[7] are their fp32 mirrors (exact below 2^24) for host-side readers. */
 int crl_optim_prepare(float* state, float base_lr, float warmup_lr_init, float lr_min, int warmup_t, int t_initial,
                       float beta1, float beta2, void* stream);
 int crl_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,

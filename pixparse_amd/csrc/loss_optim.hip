@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
     state[0] = norm;
     state[1] = bad ? 0.f : coef;
     state[2] = bad ? 1.f : 0.f;
-    if (!bad) state[3] += 1.f;          // optimiser steps actually taken (torch: state['step'] is not advanced on a skipped step)
+    if (!bad) {                         // optimiser steps actually taken (torch: state['step'] is not advanced on a skipped step)
+      state[3] += 1.f;                  // fp32 mirror (exact below 2^24)
+      reinterpret_cast<uint32_t*>(state)[11] += 1u;   // the exact count the bias corrections are computed from
+    }
     if (SCALED) {
       if (bad) { state[4] *= backoff; state[5] = 0.f; }
       else {
@@ -156,21 +159,25 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
 //   state[9]  = 1 - beta1^t,  state[10] = 1 / sqrt(1 - beta2^t)   with t = state[3] = steps taken including this one (double precision:
 //               1 - beta2^t cancels badly in fp32 for small t)
 //   state[7] += 1
+// The counts themselves are the integer words 11 (steps taken) and 12 (updates attempted) of the state vector; words 3 and 7 are their
+// fp32 mirrors for host-side readers.
 __global__ void optim_prepare_kernel(float* __restrict__ state, float base_lr, float warmup_lr_init, float lr_min, int warmup_t, int t_initial,
                                      float beta1, float beta2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double u = (double)state[7];
+  uint32_t* counts = reinterpret_cast<uint32_t*>(state);     // words 11 / 12: exact integer counts (the fp32 mirrors 3 / 7 stop at 2^24)
+  const double u = (double)counts[12];
   double lr = (double)base_lr;
   if (t_initial > 0) {
     if (u < (double)warmup_t) lr = (double)warmup_lr_init + u * ((double)base_lr - (double)warmup_lr_init) / (double)warmup_t;
     else if (u < (double)t_initial) lr = (double)lr_min + 0.5 * ((double)base_lr - (double)lr_min) * (1.0 + cos(3.14159265358979323846 * u / (double)t_initial));
     else lr = (double)lr_min;
   }
-  const double t = fmax((double)state[3], 1.0);
+  const double t = fmax((double)counts[11], 1.0);
   state[8] = (float)lr;
   state[9] = (float)(1.0 - pow((double)beta1, t));
   state[10] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
   state[7] = (float)(u + 1.0);
+  counts[12] += 1u;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,

@@ -17,7 +17,8 @@ from .. import ops
 
 STATE_FLOATS = 16  # [0] grad norm, [1] clip * unscale coefficient, [2] found inf/nan, [3] optimiser steps TAKEN,
                    # [4] GradScaler loss scale, [5] GradScaler growth tracker, [6] clip-by-value threshold (0 = off), [7] updates ATTEMPTED
-                   # (the scheduler's clock), [8] learning rate of this update, [9] 1 - beta1^t, [10] 1 / sqrt(1 - beta2^t)   (include/crl.h)
+                   # (the scheduler's clock), [8] learning rate of this update, [9] 1 - beta1^t, [10] 1 / sqrt(1 - beta2^t), [11] / [12] the
+                   # exact INTEGER counts behind [3] / [7] (uint32 bit patterns: fp32 counters stop at 2^24)   (include/crl.h)
 
 
 class ArenaAdamW:
@@ -41,7 +42,7 @@ class ArenaAdamW:
     @property
     def step_count(self) -> int:
         """optimiser steps actually taken (reads the device counter: a host sync, for checkpoints / tests only)"""
-        return int(round(float(self.state[3])))
+        return int(self.state[11:12].view(torch.int32).item())
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.g.zero_()
@@ -83,9 +84,11 @@ class ArenaAdamW:
     def set_update_count(self, n: int):
         """the scheduler's clock (updates attempted so far), e.g. after a resume"""
         self.state[7] = float(n)
+        self.state[12:13].view(torch.int32).fill_(int(n))
 
     def load_state_dict(self, sd):
         self.state[3] = float(sd['step'])
+        self.state[11:12].view(torch.int32).fill_(int(sd['step']))
         self.param_groups = [dict(g) for g in sd['param_groups']]
         self.arena.m.copy_(sd['exp_avg'])
         self.arena.v.copy_(sd['exp_avg_sq'])

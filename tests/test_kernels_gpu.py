@@ -884,6 +884,31 @@ def test_adamw_with_device_gradscaler_vs_torch(dev):
     assert sc.state_dict()['_growth_tracker'] == 0 and opt.state_dict()['step'] == 5
 
 
+def test_optimizer_counters_are_exact_beyond_2_pow_24(dev):
+    """the step / update counts live as integers on the device (state words 11 / 12): an fp32 counter would stop at 16 777 216 and freeze
+    the cosine schedule and the bias corrections; the learning rate of an update far beyond that is the scheduler's closed form"""
+    import math
+    from pixparse_amd.framework.optim import ArenaAdamW, CosineLRScheduler
+    from pixparse_amd.layers.arena import ParamArena
+    arena = ParamArena()
+    arena.add('w', (256,))
+    arena.materialize(dev)
+    opt = ArenaAdamW(arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0)
+    arena.alloc_shadow()
+    T = 40_000_000
+    sched = CosineLRScheduler(opt, t_initial=T, warmup_t=10, warmup_lr_init=0.0)
+    n0 = (1 << 24) + 5
+    opt.load_state_dict(dict(step=n0, param_groups=opt.param_groups, exp_avg=arena.m, exp_avg_sq=arena.v))
+    opt.set_update_count(n0)
+    for i in range(3):
+        arena.g.fill_(1e-3)
+        opt.step(clip_norm=1.0, zero_grad=True)
+        assert opt.step_count == n0 + i + 1, (i, opt.step_count)
+        want = 0.5 * 1e-3 * (1 + math.cos(math.pi * (n0 + i) / T))
+        assert abs(float(opt.state[8]) - want) < 1e-9, (float(opt.state[8]), want)
+    assert int(opt.state[12:13].view(torch.int32).item()) == n0 + 3
+
+
 def test_adamw_clip_by_value_vs_torch(dev):
     """timm dispatch_clip_grad mode 'value' (ref task_cruller_pretrain.py:270-278) = torch clip_grad_value_ on the UNSCALED gradient,
     applied inside the AdamW launch (state[6]); with a loss scale of 256 on the stored gradients"""
