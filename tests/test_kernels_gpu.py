@@ -90,7 +90,8 @@ def test_gemm_column_scale(dev):
     the 256x256 kernel, the 128x128 kernel, the remainder rows and the split-contraction reduce"""
     from pixparse_amd import hip, ops
     cs = 0.125 * ops.LOG2E
-    for (M, N, K, cols) in [(256 * 5 + 72, 1536, 256, 512), (300, 384, 128, 128), (256 * 64 + 232, 1024, 2048, 512), (254, 768, 8192, 256)]:
+    for (M, N, K, cols) in [(256 * 5 + 72, 1536, 256, 512), (300, 384, 128, 128), (256 * 64 + 232, 1024, 2048, 512), (254, 768, 8192, 256),
+                            (2048 + 72, 8192, 128, 4100 - 4)]:      # the last one: N >= 8192 takes the 256x128 two-per-CU kernel
         x = rnd((M, K), dev, 1.0, 1, BF16)
         w = rnd((N, K), dev, 0.05, 2, BF16)
         bias = rnd((N,), dev, 0.5, 3)
