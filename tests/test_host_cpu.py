@@ -919,3 +919,26 @@ def test_stale_library_is_refused(monkeypatch):
     monkeypatch.setattr(build, 'source_digest', lambda: {**real, 'attention.hip': '0' * 40})
     with pytest.raises(hip.HipLibraryError, match='attention.hip'):
         hip._check_not_stale(hip.LIB_PATH)
+
+
+def test_gemm_wave_quantisation_cut_decisions():
+    """the cost model of the wave-quantisation cut (gemm.hip quant_rows, measured in round 3) seen through crl_gemm_ws_bytes: a cut shows
+    as the split-K scratch of its 360 remainder rows (49 512 = 192 x 256 + 360).  Out-width 1024 with a contraction >= 2048 is cut after
+    three whole rounds (8 / 8 / 4 slabs of the remainder); K = 1024 never is; the GELU / dGELU remainders cannot be slabbed and stay uncut."""
+    from pixparse_amd import hip, ops
+    hip.load()
+    M, rem = 49512, 360
+    slab = rem * 1024 * 4
+    q = lambda *a: hip.query('crl_gemm_ws_bytes', *a)
+    assert q(hip.NN, ops.EPI_BF16, M, 1024, 4096) == 8 * slab          # fc1 dgrad
+    assert q(hip.NN, ops.EPI_BF16, M, 1024, 3072) == 6 * slab          # qkv dgrad (48 K tiles: 6 slabs of 8)
+    assert q(hip.NN, ops.EPI_BF16, M, 1024, 2048) == 4 * slab          # decoder k/v dgrad
+    assert q(hip.NT, ops.EPI_F32_RESID, M, 1024, 4096) == 8 * slab     # fc2 + residual
+    for layout, epi, N, K in ((hip.NN, ops.EPI_BF16, 1024, 1024), (hip.NT, ops.EPI_BF16, 3072, 1024), (hip.NT, ops.EPI_F32_RESID, 1024, 1024),
+                              (hip.NT, ops.EPI_BF16_GELU, 4096, 1024), (hip.NN, ops.EPI_BF16_DGELU, 4096, 1024)):
+        assert q(layout, epi, M, N, K) == 0, (layout, epi, N, K)
+    hip.call('crl_gemm_set_quant_cost', -1.0)                           # the tuning knob switches the cut off altogether
+    try:
+        assert q(hip.NN, ops.EPI_BF16, M, 1024, 4096) == 0
+    finally:
+        hip.call('crl_gemm_set_quant_cost', 1.0)
