@@ -241,6 +241,9 @@ extern "C" int crl_gemm_set_schedule(int dynamic) {
 // Kernel / split-K plan.  big = 256x256 8-phase kernel (one workgroup per CU) when it fills the chip, else the
 // 128x128 kernel.  The wgrad layout (few output tiles, very long contraction) cuts the contraction into nsplit
 // chunks: partial tiles go to fp32 slabs in the caller's scratch, then one deterministic reduce pass.
+#ifndef G_SMALL_SPLIT_MIN_NK
+#define G_SMALL_SPLIT_MIN_NK 6     // 32 = the round-2 rule (A/B)
+#endif
 struct Plan { bool big; int nsplit; int64_t chunk; };
 static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel, 3 force the 256x128 two-per-CU kernel (tests, A/B)
 #ifndef G_AUTO_2X
@@ -250,24 +253,27 @@ static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256
 static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K, bool allow_split) {
   Plan p{false, 1, 0};
   const int64_t nk = (K + 63) / 64;
-  const bool splittable = allow_split && layout == CRL_TN && (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC) && nk >= 32;
+  const bool splittable = allow_split && layout == CRL_TN && (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC);
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
   const bool k64 = (layout == CRL_TN) || (K % 64) == 0;
-  auto split_for = [&](int64_t tiles, int64_t target) {
+  // min_nk / min_chunk: the 256x256 kernel wants >= 8 K tiles per slab (its prologue stages six half-tiles); the 128x128 kernel with a
+  // handful of workgroups is LATENCY-bound at ~1.4 us per K tile (round 3, cfg-1 trace: 9 workgroups x 25 K tiles = 36 us for the Swin
+  // stage-3 weight gradients), so even short contractions are worth cutting into slabs of >= 3 K tiles there
+  auto split_for = [&](int64_t tiles, int64_t target, int64_t min_nk, int64_t min_chunk) {
     int ns = 1;
-    if (splittable && tiles < target) {
+    if (splittable && nk >= min_nk && tiles < target) {
       ns = (int)(target / tiles);
       if (ns > 16) ns = 16;
-      while (ns > 1 && nk / ns < 8) --ns;
+      while (ns > 1 && nk / ns < min_chunk) --ns;
     }
     return ns < 1 ? 1 : ns;
   };
   if (k64 && g_policy != 1 && ((M >= 256 && N >= 256) || g_policy == 2)) {
     const int ncu = crl_gemm_cus();
-    const int ns = split_for(t256, ncu);   // one workgroup per CU: aim at one full wave of split tiles
+    const int ns = split_for(t256, ncu, 32, 8);   // one workgroup per CU: aim at one full wave of split tiles
     if (t256 * ns >= (3 * ncu) / 4 || g_policy == 2) { p.big = true; p.nsplit = ns; }
   }
-  if (!p.big) p.nsplit = k64 ? split_for(t128, 3 * crl_gemm_cus()) : 1;
+  if (!p.big) p.nsplit = k64 ? split_for(t128, 3 * crl_gemm_cus(), G_SMALL_SPLIT_MIN_NK, 3) : 1;
   p.chunk = (nk + p.nsplit - 1) / p.nsplit;
   p.nsplit = (int)((nk + p.chunk - 1) / p.chunk);
   return p;
@@ -321,9 +327,13 @@ static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
 }
 // The same treatment for a WHOLE forward / dgrad GEMM with few output tiles and a very long contraction -- the LM-head dgrad of a small
 // batch: [254, 50304] x [50304, 768] = 12 tiles of 128 x 128 walking 786 K tiles each on 12 of 256 CUs (cfg-1: 0.4 ms of a 7 ms step).
-// Up to 32 chunks of the contraction as fp32 slabs + the reduce that applies the epilogue.
+// Up to 32 chunks of the contraction as fp32 slabs + the reduce that applies the epilogue.  The same latency argument holds from 32 K tiles
+// on (cfg-1 trace: the Swin stage-4 fc2 dgrad, 24 tiles x 48 K tiles, took 41 us on 24 CUs).
+#ifndef G_FEW_TILES_MIN_K
+#define G_FEW_TILES_MIN_K (64 * 32)     // 64 * 128 = the first form of the rule (A/B); rem_split itself wants >= 32 K tiles
+#endif
 static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
-  if (layout == CRL_TN || K < 64 * 128) return 1;
+  if (layout == CRL_TN || K < G_FEW_TILES_MIN_K) return 1;
   return rem_split(epilogue, M, N, K, 32);
 }
 

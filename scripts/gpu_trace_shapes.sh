@@ -2,7 +2,7 @@
 tag=${1:-r3}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-peak --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/${tag}_shapes_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.err
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-peak --no-roofline $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/${tag}_shapes_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.err
 cd $GRAFT_REPO_ROOT
 tail -1 gpurun_out/${tag}_shapes_bench.json | cut -c1-300
 f=$(find gpurun_out/prof_$tag -name "*kernel_trace.csv" | head -1)
