@@ -329,12 +329,17 @@ static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
 // batch: [254, 50304] x [50304, 768] = 12 tiles of 128 x 128 walking 786 K tiles each on 12 of 256 CUs (cfg-1: 0.4 ms of a 7 ms step).
 // Up to 32 chunks of the contraction as fp32 slabs + the reduce that applies the epilogue.  The same latency argument holds from 32 K tiles
 // on (cfg-1 trace: the Swin stage-4 fc2 dgrad, 24 tiles x 48 K tiles, took 41 us on 24 CUs).
-#ifndef G_FEW_TILES_MIN_K
-#define G_FEW_TILES_MIN_K (64 * 32)     // 64 * 128 = the first form of the rule (A/B); rem_split itself wants >= 32 K tiles
+#ifndef G_FEW_TILES_MIN_NK
+#define G_FEW_TILES_MIN_NK 16     // 128 = the first form of the rule, 32 the second (A/B)
 #endif
 static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
-  if (layout == CRL_TN || K < G_FEW_TILES_MIN_K) return 1;
-  return rem_split(epilogue, M, N, K, 32);
+  if (layout == CRL_TN || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
+  const int64_t nk = K / 64, tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (nk < G_FEW_TILES_MIN_NK || tiles >= 128) return 1;
+  int ns = (int)(384 / tiles);
+  if (ns > 32) ns = 32;
+  while (ns > 1 && nk / ns < 4) --ns;       // slabs of >= 4 K tiles
+  return ns;
 }
 
 extern "C" int crl_gemm_set_policy(int policy) {

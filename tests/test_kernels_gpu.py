@@ -473,8 +473,8 @@ def test_gemm_few_tiles_long_contraction_split(dev):
     from pixparse_amd import hip, ops
     M, N, K = 254, 768, 50304
     assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, K) == 32 * M * N * 4
-    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 4096) == 8 * M * N * 4    # 64 K tiles: 8 slabs of 8
-    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 1024) == 0          # short contraction: one launch
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 4096) == 16 * M * N * 4   # 64 K tiles: 16 slabs of 4
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 512) == 0           # short contraction: one launch
     dy = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((K, N), dev, 0.02, 2, BF16)
     out = torch.empty(M, N, dtype=BF16, device=dev)
