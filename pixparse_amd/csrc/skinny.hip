@@ -167,6 +167,8 @@ extern "C" int crl_linear_skinny_ln_bf16(int epilogue, int M, int64_t N, int64_t
            x_f32, ldx, gamma, beta, eps, h_f32, ldh};
   const unsigned grid = (unsigned)((N + 15) / 16);
   const size_t lds = (size_t)M * (K + SK_PAD) * sizeof(u16);
+  CRL_CHECK(lds <= 60 * 1024, "%s: %d rows of %lld features need %zu bytes of LDS (limit 60 KiB: fewer rows, or crl_layernorm_fwd + crl_linear_skinny_bf16)",
+            who, M, (long long)K, lds);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool wide = grid <= 512 && K >= 512;
 #define SK_LAUNCH_LN(E) do { if (wide) linear_skinny_kernel<E, true, 16><<<grid, 1024, lds, s>>>(a); else linear_skinny_kernel<E, true, 4><<<grid, 256, lds, s>>>(a); } while (0)

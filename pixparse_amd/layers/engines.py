@@ -582,7 +582,8 @@ class BartEngine(_Base):
     def _ln_lin(self, ln_name, t32, key, eps, w, b, out, epi=ops.EPI_BF16, **row):
         """h = LayerNorm(t32), out = epilogue(bf16(h) @ w^T + b); returns the fp32 h (the next residual).  Decode rows: ONE launch
         (crl_linear_skinny_ln_bf16, every workgroup normalises the <= 16 rows for itself); more rows: ln_fwd + the GEMM"""
-        if t32.shape[0] <= ops.SKINNY_MAX_ROWS and w.shape[0] >= t32.shape[1] and _DECODE_LN_FUSION:
+        if (t32.shape[0] <= ops.SKINNY_MAX_ROWS and w.shape[0] >= t32.shape[1] and _DECODE_LN_FUSION
+                and t32.shape[0] * (t32.shape[1] + 32) * 2 <= 60 * 1024):          # the normalised rows live in LDS
             h = self.buf(key + '.y32', tuple(t32.shape), F32)
             ops.linear_skinny_ln(t32, self.P(ln_name + '.weight'), self.P(ln_name + '.bias'), eps, h, w, b, out, epi, **row)
             return h
