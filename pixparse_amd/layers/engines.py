@@ -24,6 +24,7 @@ from ..ops import BF16, F32, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RE
 from .arena import ParamArena
 
 
+_FUSE_CROSS_KV = os.environ.get('PIXPARSE_AMD_FUSE_CROSS_KV', '1') != '0'           # A/B switch: one K/V projection GEMM for all decoder layers
 _DECODE_LN_FUSION = os.environ.get('PIXPARSE_AMD_DECODE_LN_FUSION', '1') != '0'     # A/B switch of the generation step (scripts/bench_generate.py)
 
 
@@ -514,6 +515,23 @@ class BartEngine(_Base):
     def fb(self, kind, lp, attn, first, count):   # fused bias [count*D]
         return self._fused(kind, lp + f'{attn}.{first}.bias', count, (count * self.D,))
 
+    def _kv_fused(self, Me: int) -> bool:
+        return self.L > 1 and (Me + 256) * self.L * 2 * self.D * 2 < (1 << 32) and _FUSE_CROSS_KV
+
+    def _kv_all(self, enc16, Me):
+        if not self._kv_fused(Me):
+            return None
+        dp, D, L = self.DP, self.D, self.L
+        w_all = self.buf('kv.w_all', (L * 2 * D, D), BF16)
+        b_all = self.buf('kv.b_all', (L * 2 * D,), F32)
+        for i in range(L):
+            lp = dp + f'layers.{i}.'
+            w_all[2 * D * i:2 * D * (i + 1)].copy_(self.fw('w', lp, 'encoder_attn', 'k_proj', 2))
+            b_all[2 * D * i:2 * D * (i + 1)].copy_(self.fb('p', lp, 'encoder_attn', 'k_proj', 2))
+        kv_all = self.buf('kv.all', (Me, L * 2 * D), BF16)
+        ops.linear_fwd(enc16, w_all, b_all, kv_all)
+        return kv_all
+
     def forward(self, ids: torch.Tensor, enc16: torch.Tensor, S: int):
         """ids [B, T] int64; enc16 bf16 [B*S, D] -> logits buffer bf16 [B*T, Vp]."""
         dp, D, F_, H = self.DP, self.D, self.F, self.heads
@@ -530,6 +548,11 @@ class BartEngine(_Base):
         # attention-probability dropout (sites 200 + 2 i: self, 201 + 2 i: cross; hf BartAttention dropout = config.attention_dropout) and
         # activation dropout behind the GELU (site 300 + i; hf:384): live only when the DropSpec carries p_attn / p_act (bart-base)
         drop, p_act = self.drop, (self.drop.p_act if self.drop is not None else 0.0)
+        # The cross-attention K / V projections of ALL layers read the same encoder output: one GEMM [Me, D] x [L * 2D, D]^T into one
+        # [Me, L * 2D] buffer (layer i's k | v are column block i), and in backward() one dgrad GEMM over the L * 2D columns instead of L
+        # GEMMs that each read-modify-write the fp32 d(encoder output) (cfg-3: 10 x 267 us -> 1.66 ms).  The weights of the L layers are
+        # gathered into one operand per step (L copies of 4 MB).  Off when the fused buffer would pass the GEMM's 4 GiB operand limit.
+        kv_all = self._kv_all(enc16, Me)
         for i in range(self.L):
             lp, k = dp + f'layers.{i}.', f'l{i}'
             qkv = self.buf(k + '.qkv', (M, 3 * D), BF16)
@@ -546,9 +569,12 @@ class BartEngine(_Base):
             q2 = self.buf(k + '.q2', (M, D), BF16)
             ops.linear_fwd(h1b, self.W(lp + 'encoder_attn.q_proj.weight'), self.P(lp + 'encoder_attn.q_proj.bias'), q2,
                            colscale=scale * ops.LOG2E, colscale_cols=D)
-            kv2 = self.buf(k + '.kv2', (Me, 2 * D), BF16)
-            ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
-            kv3 = kv2.view(B, S, 2 * D)
+            if kv_all is not None:
+                kv3 = kv_all.view(B, S, self.L * 2 * D)[:, :, 2 * D * i:2 * D * (i + 1)]
+            else:
+                kv2 = self.buf(k + '.kv2', (Me, 2 * D), BF16)
+                ops.linear_fwd(enc16, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), self.fb('p', lp, 'encoder_attn', 'k_proj', 2), kv2)
+                kv3 = kv2.view(B, S, 2 * D)
             o2 = self.buf(k + '.o2', (M, D), BF16)
             lse2 = self.buf(k + '.lse2', (B, H, T), F32)
             ops.attn_fwd(q2.view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], o2.view(B, T, D), lse2, H, scale, False, drop=drop, site=201 + 2 * i,
@@ -725,7 +751,9 @@ class BartEngine(_Base):
         dhb = self.buf('dhb', (M, D), BF16)
         do = self.buf('do', (M, D), BF16)
         dq2 = self.buf('dq2', (M, D), BF16)
-        dkv2 = self.buf('dkv2', (Me, 2 * D), BF16)
+        fused_kv = self._kv_fused(Me)
+        dkv_all = self.buf('kv.dall', (Me, self.L * 2 * D), BF16) if fused_kv else None
+        dkv2 = None if fused_kv else self.buf('dkv2', (Me, 2 * D), BF16)
         dqkv = self.buf('dqkv', (M, 3 * D), BF16)
         delta = self.buf('delta', (2, B, H, T), F32)
         if self.L == 0:
@@ -746,13 +774,19 @@ class BartEngine(_Base):
             self._branch_bwd(lp + 'encoder_attn_layer_norm', k + '.ln2', g('.t2'), dt, dhb, dt2, dtb, lp + 'encoder_attn.out_proj', 2 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'encoder_attn.out_proj.weight'), do)
             self.lin_wgrad(lp + 'encoder_attn.out_proj', dtb, g('.o2'), has_bias=False)
-            kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
+            if fused_kv:
+                kv3 = Tb[tg + 'kv.all'].view(B, S, self.L * 2 * D)[:, :, 2 * D * i:2 * D * (i + 1)]
+                dkv2 = dkv_all[:, 2 * D * i:2 * D * (i + 1)]                  # column block i: a strided [Me, 2D] operand
+                dkv3 = dkv_all.view(B, S, self.L * 2 * D)[:, :, 2 * D * i:2 * D * (i + 1)]
+            else:
+                kv3, dkv3 = g('.kv2').view(B, S, 2 * D), dkv2.view(B, S, 2 * D)
             ops.attn_bwd(g('.q2').view(B, T, D), kv3[:, :, 0:D], kv3[:, :, D:], g('.o2').view(B, T, D), do.view(B, T, D), g('.lse2'), delta,
                          dq2.view(B, T, D), dkv3[:, :, 0:D], dkv3[:, :, D:], H, scale, False, drop=drop, site=201 + 2 * i, q_prescaled=True)
             ops.linear_dgrad(dq2, self.W(lp + 'encoder_attn.q_proj.weight'), dhb)
             self.lin_wgrad(lp + 'encoder_attn.q_proj', dq2, g('.ln1.y16'))
             # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
-            ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32 if i == self.L - 1 else EPI_F32_ACC)
+            if not fused_kv:
+                ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32 if i == self.L - 1 else EPI_F32_ACC)
             ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
             ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
@@ -768,6 +802,8 @@ class BartEngine(_Base):
             dy32 = dt  # residual-path gradient for the layer below (dt now holds d t1)
             if on_layer_done:
                 on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')
+        if fused_kv:       # d(encoder output) = [dK_0 | dV_0 | ... | dK_{L-1} | dV_{L-1}] . [W_0; ...; W_{L-1}]: ONE GEMM, fp32 output written once
+            ops.linear_dgrad(dkv_all, Tb[tg + 'kv.w_all'], denc, EPI_F32)
         # ---- h0 = LN(emb)
         demb = self.buf('demb', (M, D), F32)
         if self._hidden_drop():        # the mask of site 0 on both gradient streams arriving at the embedding LayerNorm output
