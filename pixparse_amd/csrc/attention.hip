@@ -723,58 +723,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   }
 }
 
-// ======================================================================================= fused single-pass backward
+// ======================================================================================= single-pass backward
 // dK, dV AND dQ from ONE recomputation of S and dP: 5 MFMA products per (query, key) tile instead of the 7 of the two-pass form above
 // (guide Appendix B "Attention backward").  The price is a sum of dQ over the workgroups that share a (b, h): it is paid with plain
 // stores + a deterministic reduce pass (no float atomics: at N = 6189 they would run at the chip's 1.3 TB/s atomic rate, and the sum
 // would depend on arrival order).
 //
-// Workgroup = 8 waves = 512 keys of one (b, h), one workgroup per CU; wave w owns keys 64 w .. 64 w + 63 (dK^T, dV^T of its keys: 128
-// accumulator registers, V fragments in 32 more); the workgroup sweeps the query tiles of 64 rows.  Per tile and wave:
-//   S = Q.K^T, dP = dO.V^T (key on the lane, seeded with -lse/scale and -delta)  ->  P = exp2(c S'), dS = P o dP'   [32 MFMAs]
-//   dV^T += dO^T.P, dK^T += Q^T.dS   (accumulators as the next operand, Q^T / dO^T by transposed LDS reads)          [32 MFMAs]
-//   dS (bf16) -> LDS as a [key][query] tile, one per wave;  barrier
-//   dQ^T block [32 d x 32 q] += K^T.dS^T over the 256 keys of the wave's key half (both operands by transposed reads) [16 MFMAs]
-// The two key halves of a workgroup (waves 0-3 / 4-7) each emit their own partial dQ -- bf16 [B, Nq, H*64] "slab" number
-// 2 * keytile + half -- so ceil(Nk / 256) slabs per head; attn_dq_reduce_kernel adds them in slab order in fp32, applies the softmax
-// scale and rounds once more to the bf16 dQ the following GEMMs read.  (A partial is rounded to bf16 before the sum: with 25 slabs of
-// comparable magnitude that adds about one more bf16 rounding to dQ -- 3.0e-3 instead of 2.4e-3 relative L2 against fp32 -- well inside
-// the tolerance of every parity test.)
-// MEASURED (profiles/r3_attn_fused_experiment.txt, B 8, H 16, N 6189, back to back on one box): this kernel 3.63 ms + reduce 0.47 ms +
-// row constants 0.05 ms = 4.15 ms against 2.30 + 1.73 = 4.03 ms for the two passes: it executes 71 % of their MFMAs at 79 % of their
-// rate.  The limit is the LDS, not the matrix pipe: per 32 x 32 block a wave moves about 190 LDS cycles (row constants, Q / K / dO row
-// fragments, four transposed fragments, the dS tile written and read back for dQ) against 64-96 in the two-pass kernels, with 8 waves per
-// CU instead of 12 -- the LDS array is busy for as long as the 20 MFMAs of the block take.  The registers that would cut the traffic (K
-// fragments, shared A operands for the two key blocks) do not exist: 255 are in use.  Hence: correct, deterministic, kept as mode 2, and
-// NOT the default.
-// (A 4-wave / 256-key workgroup, two per CU, would overlap one workgroup's barriers with the other's work, but its per-wave state --
-// 128 accumulators + 32 V registers + the S / dP block -- does not fit 256 registers under hipcc next to exactly 80 KiB of LDS: built,
-// it spilled the V fragments into scratch.)
-// LDS: K [512 keys x 64 d] as 8 tiles of 8 KiB | dS 8 tiles of 8 KiB | Q tile | dO tile | -lse/scale, -delta of the tile.
-// vmcnt discipline (loads and stores count together, in issue order): per tile a wave issues its LDS-DMA loads FIRST (right after the
-// barrier that frees the Q / dO tiles) and then exactly four slab stores; the wait at the top of the next tile is vmcnt(4): the loads
-// have landed, the stores may still be in flight.  The kernel must not spill inside the loop (a scratch reload is a VMEM load the
-// compiler waits for with vmcnt(0): right behind the DMA issue that would expose the whole fetch latency on every tile).
-constexpr int FUSED_THREADS = 512;
-constexpr int F_K = 0, F_DS = 65536, F_Q = 131072, F_DO = 139264, F_RC = 147456;
-constexpr int FUSED_LDS = F_RC + 512;
+// Workgroup = 4 waves = 256 keys of one (b, h), ONE workgroup per CU: every wave is alone on its SIMD and owns the whole 512-entry
+// register file.  Wave w owns keys 64 w .. 64 w + 63: dK^T and dV^T of its keys (128 accumulator registers), the K and V ROW fragments of
+// its keys (64 registers: the B operands of S and dP never touch LDS) and the K^T fragments of the workgroup's 256 keys for its dQ block
+// (64 registers).  The workgroup sweeps the query tiles of 64 rows; per tile and wave:
+//   S = Q.K^T, dP = dO.V^T (key on the lane, seeded with -lse/scale and -delta)  ->  P = exp2(c S'), dS = P o dP'   [32 MFMAs; every Q / dO
+//                                                                                  row fragment feeds the MFMAs of BOTH key blocks]
+//   dV^T += dO^T.P, dK^T += Q^T.dS   (accumulators as the next operand; every transposed Q^T / dO^T fragment feeds both key blocks) [32]
+//   dS (bf16) -> LDS as a [key][query] tile, one per wave, double-buffered;  ONE barrier per tile
+//   dQ^T block [32 d x 32 q] of the PREVIOUS tile += K^T.dS^T over the workgroup's 256 keys (dS^T by transposed reads)            [16]
+// so only dS crosses LDS.  The partial dQ of key block kb goes to the bf16 [B, Nq, H*64] slab number kb; attn_dq_reduce_kernel adds the
+// ceil(Nk / 256) slabs in slab order in fp32, applies the softmax scale and rounds once more to the bf16 dQ the following GEMMs read.
+// (A partial is rounded to bf16 before the sum: with 25 slabs of comparable magnitude that adds about one more bf16 rounding to dQ --
+// 3.0e-3 instead of 2.4e-3 relative L2 against fp32 -- well inside the tolerance of every parity test.)
+// LDS: ring of 2 x [Q tile | dO tile | -lse/scale, -delta of the tile] | 2 x dS [4 waves][64 keys][64 q]  (K is staged once through the
+// first dS buffer for the K^T fragments).
+// vmcnt discipline (loads and stores count together, in issue order): per tile a wave issues its five LDS-DMA loads FIRST (right after the
+// barrier that frees the ring slot) and then exactly four slab stores; the wait at the top of the next tile is vmcnt(4): the loads have
+// landed, the stores may still be in flight.
+constexpr int SP_SLOT = 2 * 8192 + 512;
+constexpr int SP_DS = 2 * SP_SLOT;
+constexpr int SP_DUMMY = SP_DS + 2 * 32768;
+constexpr int SP_LDS = SP_DUMMY + 256;
 
-template <int DUMMY>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void attn_bwd_fused_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
+template <bool PRE>
+__global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const char* const k_lds = smem + F_K;           // [8][64 keys][64 d]
-  char* const ds_lds = smem + F_DS;               // [8][64 keys][64 q]
-  const char* const q_lds = smem + F_Q;           // [64 q][64 d]
-  const char* const do_lds = smem + F_DO;
-  const float* const lse_s = reinterpret_cast<const float*>(smem + F_RC);   // 64 x -lse/scale, then 64 x -delta
-  const float* const del_s = lse_s + 64;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wq = wave & 3;       // staging group (256 threads each) = key half of the dQ phase, wave within it
   const int ki = lane & 31, hh = lane >> 5;
-  int bh, ktile;
-  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, ktile);
+  int bh, kblk;
+  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, kblk);
   const int b = bh / a.H, h = bh % a.H;
 
   const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
@@ -785,26 +770,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void attn_bwd_fused_kernel(const 
   const u32x4 rd = make_srd(a.delta + ((int64_t)b * a.H + h) * a.Nq, (uint32_t)a.Nq * 4u);          // -delta
   const uint32_t sbase = lds_addr_of(smem);
   const LaneAddr la = make_lane_addr(lane);
-  const int tg = tid & 255;                       // thread index inside its staging group
-  const StageOff sqd = make_stage_off(tg, grp ? a.do_rs : a.q_rs), sk = make_stage_off(tg, a.k_rs);
+  const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
 
-  const int key_wg = ktile * 512;
+  const int key_wg = kblk * 256;
   const int key0 = key_wg + wave * 64;            // this wave's 64 keys
   const bool wave_live = key0 < a.Nk;
-  // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: their dS contributes nothing to dQ); group g stages tiles g, g+2, ..
+  const bool kmask = key0 + 64 > a.Nk;            // some of them lie past Nk
+  // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: their dS contributes nothing to dQ)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t = 2 * j + grp;
-    stage64(rk, sbase + F_K + t * 8192, sk, key_wg + 64 * t, a.k_rs, wq);
-  }
-  bf16x8 vf[2][4];
+  for (int j = 0; j < 4; ++j) stage64(rk, sbase + SP_DS + j * 8192, sk, key_wg + 64 * j, a.k_rs, wave);
+  bf16x8 kf[2][4], vf[2][4];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int krow = min(key0 + 32 * kb + ki, a.Nk - 1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[kb][ks] = *reinterpret_cast<const bf16x8*>(a.k + b * a.k_bs + (int64_t)krow * a.k_rs + h * 64 + 16 * ks + 8 * hh);
       vf[kb][ks] = *reinterpret_cast<const bf16x8*>(a.v + b * a.v_bs + (int64_t)krow * a.v_rs + h * 64 + 16 * ks + 8 * hh);
+    }
   }
+  // a key past Nk is switched off through the seed of S (exp2(-inf) = 0: P = dS = 0 whatever the clamped K / V rows hold)
+  const float kneg0 = (kmask && key0 + ki >= a.Nk) ? -INFINITY : 0.f, kneg1 = (kmask && key0 + 32 + ki >= a.Nk) ? -INFINITY : 0.f;
   f32x16 dv[2][2], dk[2][2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -813,19 +799,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void attn_bwd_fused_kernel(const 
   const float c = a.scale * LOG2E;
   const int nqt64 = (a.Nq + 63) / 64;
 
-  // Q tile + -lse/scale by group 0, dO tile + -delta by group 1: three DMA instructions per wave and tile (waves 0 / 4: the row constants;
-  // the other waves re-issue their second piece so that EVERY wave has issued exactly three loads -- the vmcnt(4) below counts on it)
-  const u32x4 rqd = grp ? rdo : rq;
-  const u32x4 rlc = grp ? rd : rl;
-  const uint32_t lds_qd = sbase + (grp ? F_DO : F_Q), lds_rc = sbase + F_RC + (grp ? 256 : 0);
-  auto stage = [&](int t) {
-    stage64(rqd, lds_qd, sqd, t * 64, grp ? a.do_rs : a.q_rs, wq);
-    if (wq == 0) dma4(rlc, lds_rc, (uint32_t)lane * 4u, (uint32_t)t * 256u);
-    else dma16(rqd, lds_qd + 4096u + (uint32_t)wq * 1024u, sqd.v, (uint32_t)((int64_t)(t * 64) * (grp ? a.do_rs : a.q_rs) * 2) + (uint32_t)(32 * (grp ? a.do_rs : a.q_rs) * 2));
+  // five DMA instructions per wave and tile: two pieces of the Q tile, two of the dO tile, one row-constant vector (waves 2 / 3: a dummy)
+  auto stage = [&](int slot, int t) {
+    const uint32_t base = sbase + slot * SP_SLOT;
+    stage64(rq, base, sq, t * 64, a.q_rs, wave);
+    stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
+    const uint32_t dst = wave == 0 ? base + 16384 : wave == 1 ? base + 16384 + 256 : sbase + SP_DUMMY;
+    dma4(wave == 1 ? rd : rl, dst, (uint32_t)lane * 4u, (uint32_t)t * 256u);
   };
-  const char* const my_k = k_lds + wave * 8192;
-  char* const my_ds = ds_lds + wave * 8192;
-  const int qh = wq >> 1, dbq = wq & 1;           // dQ phase: this wave's block = d rows 32 dbq.., q columns 32 qh..
+  const int qh = wave >> 1, dbq = wave & 1;       // dQ phase: this wave's block = d rows 32 dbq.., q columns 32 qh..
   // the transposed-read addresses of that block, selected ONCE (indexing la.tr with a wave-dependent index inside the loop would put the
   // array into scratch memory)
   const uint32_t trk0 = dbq ? la.tr[1][0] : la.tr[0][0], trk1 = dbq ? la.tr[1][1] : la.tr[0][1];   // K^T operand (d block dbq)
@@ -836,103 +818,115 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void attn_bwd_fused_kernel(const 
     typedef short short8v __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
-  // partial dQ of this key half: rows q of batch b in slab 2 * ktile + grp; bounds-checked stores drop the rows past Nq
-  const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(slabs + (int64_t)(2 * ktile + grp) * slab_stride + (int64_t)b * a.Nq * (a.H * 64), 0,
+  // partial dQ of this key block: rows q of batch b in slab kblk; bounds-checked stores drop the rows past Nq
+  const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(slabs + (int64_t)kblk * slab_stride + (int64_t)b * a.Nq * (a.H * 64), 0,
                                                                         (int)((int64_t)a.Nq * (a.H * 64) * 2), 0x00020000);
-  const bool half_live = key_wg + grp * 256 < a.Nk;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16x8 ka[16];                                   // K^T [32 d of block dbq][256 keys]: the A operands of this wave's dQ block
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) ka[kk] = tr_read(smem + SP_DS + (kk >> 2) * 8192, trk0, trk1, 16 * (kk & 3));
 
-  stage(0);
-  for (int t = 0; t < nqt64; ++t) {
-    // tile t (and, the first time, K) landed -- the four slab stores of the previous tile may still be in flight -- and every wave is
-    // done with the dS tiles of tile t - 1
-    if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __syncthreads();
-    if (wave_live) {
+  auto phase_a = [&](auto slotc, int t) {
+    constexpr int SLOT = decltype(slotc)::value;
+    const char* ql = smem + SLOT * SP_SLOT;
+    const char* dol = ql + 8192;
+    const float* lse_s = reinterpret_cast<const float*>(ql + 16384);
+    const float* del_s = lse_s + 64;
+    char* my_ds = smem + SP_DS + SLOT * 32768 + wave * 8192;
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x16 s, dp;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
-            const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
-            s[4 * g4] = L.x; s[4 * g4 + 1] = L.y; s[4 * g4 + 2] = L.z; s[4 * g4 + 3] = L.w;
-            dp[4 * g4] = Dl.x; dp[4 * g4 + 1] = Dl.y; dp[4 * g4 + 2] = Dl.z; dp[4 * g4 + 3] = Dl.w;
-          }
-          __builtin_amdgcn_s_setprio(PRIO_MFMA);
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(frag_row(q_lds, la, 32 * qb, ks), frag_row(my_k, la, 32 * kb, ks), s);
-            dp = mfma32(frag_row(do_lds, la, 32 * qb, ks), vf[kb][ks], dp);
-          }
-          __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[r] * c);
-            s[r] = p;
-            dp[r] = p * dp[r];
-          }
-          __builtin_amdgcn_s_setprio(PRIO_MFMA);
-          const int row = 32 * kb + ki;
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss) {
-            const bf16x8 pf = acc_frag(s, ss), dsf = acc_frag(dp, ss);
-            dv[kb][0] = mfma32(frag_tr(do_lds, la, 32 * qb + 16 * ss, 0), pf, dv[kb][0]);
-            dv[kb][1] = mfma32(frag_tr(do_lds, la, 32 * qb + 16 * ss, 1), pf, dv[kb][1]);
-            dk[kb][0] = mfma32(frag_tr(q_lds, la, 32 * qb + 16 * ss, 0), dsf, dk[kb][0]);
-            dk[kb][1] = mfma32(frag_tr(q_lds, la, 32 * qb + 16 * ss, 1), dsf, dk[kb][1]);
-            // the dS block (32 keys x 32 queries) -> this wave's [key][query] tile: the operand registers ARE the bf16 pairs of query rows
-            // 8 (2 ss) + 4 hh + 0..3 and 8 (2 ss + 1) + 4 hh + 0..3: two 8-byte stores per lane
-            const uint4 dw = __builtin_bit_cast(uint4, dsf);
-            const int c0 = 4 * qb + 2 * ss;
-            *reinterpret_cast<uint2*>(my_ds + row * 128 + ((c0 ^ swz64(row)) << 4) + 8 * hh) = uint2{dw.x, dw.y};
-            *reinterpret_cast<uint2*>(my_ds + row * 128 + (((c0 + 1) ^ swz64(row)) << 4) + 8 * hh) = uint2{dw.z, dw.w};
-          }
-          __builtin_amdgcn_s_setprio(0);
-        }
-      }
-    }
-    __syncthreads();            // dS of the tile complete; nobody reads Q / dO / the row constants of tile t any more
-    // next tile's loads: ALL loads of the iteration are issued here, before its four stores (the last iteration re-stages its own tile:
-    // the instruction count per iteration stays fixed)
-    stage(t + 1 < nqt64 ? t + 1 : t);
-    {
-      // dQ^T block [32 d x 32 q] of this wave over the 256 keys of its half: K^T (d x key) and dS^T (key x q) both read transposed
-      f32x16 dq = zero16();
-      if (half_live) {
-        __builtin_amdgcn_s_setprio(PRIO_MFMA);
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          const int tl = 4 * grp + sub;
-          if (key_wg + 64 * tl < a.Nk) {       // wave-uniform: tiles of waves without keys hold no dS
-            const char* kt_ = k_lds + tl * 8192;
-            const char* dt_ = ds_lds + tl * 8192;
-            // all sixteen transposed reads of the tile first (the S / dP registers are free in this phase), then the four MFMAs: with
-            // read -> wait -> MFMA one by one the two waves of a SIMD, which run this phase in lockstep behind the barrier, leave the pipe idle
-            bf16x8 ka[4], sa[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { ka[kk] = tr_read(kt_, trk0, trk1, 16 * kk); sa[kk] = tr_read(dt_, trs0, trs1, 16 * kk); }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dq = mfma32(ka[kk], sa[kk], dq);
-          }
-        }
-        __builtin_amdgcn_s_setprio(0);
-      }
-      // always four stores per wave (rows past Nq and the slabs of key halves without keys fall off the descriptor)
-      const uint32_t row_off = half_live ? (uint32_t)(t * 64 + 32 * qh + ki) * (uint32_t)(a.H * 64 * 2) + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2) : 0xfffffff0u;
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s[2], dp[2];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 w;
-        w[0] = pack_bf2(dq[4 * g4], dq[4 * g4 + 1]);
-        w[1] = pack_bf2(dq[4 * g4 + 2], dq[4 * g4 + 3]);
-        __builtin_amdgcn_raw_buffer_store_b64(w, rslab, row_off + (half_live ? 16 * g4 : 0), 0, 0);
+        const float4 L = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+        const float4 Dl = *reinterpret_cast<const float4*>(del_s + 32 * qb + 8 * g4 + 4 * hh);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          s[kb][4 * g4] = L.x; s[kb][4 * g4 + 1] = L.y; s[kb][4 * g4 + 2] = L.z; s[kb][4 * g4 + 3] = L.w;
+          dp[kb][4 * g4] = Dl.x; dp[kb][4 * g4 + 1] = Dl.y; dp[kb][4 * g4 + 2] = Dl.z; dp[kb][4 * g4 + 3] = Dl.w;
+        }
+      }
+      if (kmask) {   // wave-uniform: only the last key block of a head pays
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[0][r] += kneg0; s[1][r] += kneg1; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 fq = frag_row(ql, la, 32 * qb, ks), fdo = frag_row(dol, la, 32 * qb, ks);
+        s[0] = mfma32(fq, kf[0][ks], s[0]);
+        s[1] = mfma32(fq, kf[1][ks], s[1]);
+        dp[0] = mfma32(fdo, vf[0][ks], dp[0]);
+        dp[1] = mfma32(fdo, vf[1][ks], dp[1]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(PRE ? s[kb][r] : s[kb][r] * c);
+          s[kb][r] = p;
+          dp[kb][r] = p * dp[kb][r];
+        }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 tdo0 = frag_tr(dol, la, 32 * qb + 16 * ss, 0), tdo1 = frag_tr(dol, la, 32 * qb + 16 * ss, 1);
+        const bf16x8 tq0 = frag_tr(ql, la, 32 * qb + 16 * ss, 0), tq1 = frag_tr(ql, la, 32 * qb + 16 * ss, 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const bf16x8 pf = acc_frag(s[kb], ss), dsf = acc_frag(dp[kb], ss);
+          mfma32_acc_a(tdo0, pf, dv[kb][0]);
+          mfma32_acc_a(tdo1, pf, dv[kb][1]);
+          mfma32_acc_a(tq0, dsf, dk[kb][0]);
+          mfma32_acc_a(tq1, dsf, dk[kb][1]);
+          // the dS block (32 keys x 32 queries) -> this wave's [key][query] tile: the operand registers ARE the bf16 pairs of query rows
+          // 8 (2 ss) + 4 hh + 0..3 and 8 (2 ss + 1) + 4 hh + 0..3: two 8-byte stores per lane
+          const uint4 dw = __builtin_bit_cast(uint4, dsf);
+          const int row = 32 * kb + ki, c0 = 4 * qb + 2 * ss;
+          *reinterpret_cast<uint2*>(my_ds + row * 128 + ((c0 ^ swz64(row)) << 4) + 8 * hh) = uint2{dw.x, dw.y};
+          *reinterpret_cast<uint2*>(my_ds + row * 128 + (((c0 + 1) ^ swz64(row)) << 4) + 8 * hh) = uint2{dw.z, dw.w};
+        }
       }
     }
+  };
+  // dQ^T block [32 d x 32 q] of this wave for query tile t over the workgroup's 256 keys (K^T from registers, dS^T by transposed reads),
+  // then always four stores per wave (rows past Nq -- and everything when t < 0 -- fall off the descriptor)
+  auto phase_b = [&](auto slotc, int t) {
+    constexpr int SLOT = decltype(slotc)::value;
+    const char* dsr = smem + SP_DS + SLOT * 32768;
+    f32x16 dq = zero16();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (key_wg + 64 * w < a.Nk) {       // wave-uniform: tiles of waves without keys hold no dS
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dq = mfma32(ka[4 * w + kk], tr_read(dsr + w * 8192, trs0, trs1, 16 * kk), dq);
+      }
+    }
+    const uint32_t row_off = t >= 0 ? (uint32_t)(t * 64 + 32 * qh + ki) * (uint32_t)(a.H * 64 * 2) + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2) : 0xfffffff0u;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 w2;
+      w2[0] = pack_bf2(dq[4 * g4], dq[4 * g4 + 1]);
+      w2[1] = pack_bf2(dq[4 * g4 + 2], dq[4 * g4 + 3]);
+      __builtin_amdgcn_raw_buffer_store_b64(w2, rslab, row_off + (t >= 0 ? 16 * g4 : 0), 0, 0);
+    }
+  };
+  auto iter = [&](auto slotc, int t) {
+    constexpr int SLOT = decltype(slotc)::value;
+    // tile t landed -- the four slab stores of the previous iteration may still be in flight -- and, behind the barrier, every wave
+    // is done with tile t - 1 (its ring slot and the dS buffer of tile t - 2 are free, dS of tile t - 1 is complete)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    stage(SLOT ^ 1, min(t + 1, nqt64 - 1));
+    if (t < nqt64 && wave_live) phase_a(slotc, t);
+    phase_b(ic<(SLOT ^ 1)>{}, t - 1);
+  };
+  for (int t = 0; t <= nqt64; t += 2) {
+    iter(ic<0>{}, t);
+    if (t + 1 <= nqt64) iter(ic<1>{}, t + 1);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   const float sc = a.scale;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
@@ -1120,19 +1114,22 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     CRL_CHECK(((uintptr_t)ws % 16) == 0 && (dq_rs % 8) == 0, "%s: workspace / dq must be 16-byte aligned", who);
     static bool configured = false;
     if (!configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-      if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, FUSED_LDS, hipGetErrorString(e)); return -2; }
+      for (const void* f : {reinterpret_cast<const void*>(&attn_bwd_sp_kernel<false>), reinterpret_cast<const void*>(&attn_bwd_sp_kernel<true>)}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+        if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, SP_LDS, hipGetErrorString(e)); return -2; }
+      }
       configured = true;
     }
     a.fused_delta = 0;
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
-    a.nkt = (Nk + 511) / 512;
-    const int nslab = (Nk + 255) / 256;
+    a.nkt = (Nk + 255) / 256;
+    const int nslab = a.nkt;
     const int64_t slab_stride = (int64_t)B * Nq * H * 64;
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
-    attn_bwd_fused_kernel<0><<<(unsigned)a.nkt * B * H, FUSED_THREADS, FUSED_LDS, s>>>(a, (u16*)ws, slab_stride);
+    if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
+    else attn_bwd_sp_kernel<false><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
     CRL_PROF_STOP(CRL_K_ATTN_BWD_FUSED, stream);
     CRL_LAUNCH_CHECK("crl_attn_bwd(fused)");
     const int64_t n8 = (int64_t)B * Nq * (H * 64 / 8);

@@ -81,6 +81,10 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 __device__ __forceinline__ void mfma32_acc(bf16x8 a, bf16x8 b, f32x16& c) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// the same with the accumulator in the ACCUMULATOR half of the register file (a kernel with one wave per SIMD owns 256 + 256 registers)
+__device__ __forceinline__ void mfma32_acc_a(bf16x8 a, bf16x8 b, f32x16& c) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 // row index (within a 32-row block) of accumulator register r for lane half hh
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
