@@ -11,7 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcruller_hip.so')
 SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm2x.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'dropout.hip', 'debug.hip', 'capi.cpp']
-HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", os.path.join('..', '..', 'include', 'crl.h')]
+HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", "attn_bwd_sp_body.inc", os.path.join('..', '..', 'include', 'crl.h')]
+# generated sources: (generator script, output) -- the output is committed; it is regenerated when the script is newer
+GENERATED = [('gen_attn_bwd_sp.py', 'attn_bwd_sp_body.inc')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # per-file extras: hipcc's SLP vectoriser packs the softmax / dS multiplies of the attention kernels into v_pk_mul_f32 on
 # misaligned register pairs and then spends ~25 v_mov / v_perm / v_alignbit per 32x32 block re-assembling the bf16 MFMA
@@ -45,8 +47,18 @@ def source_digest() -> dict:
     return {f: hashlib.sha1(open(os.path.join(CSRC, f), 'rb').read()).hexdigest() for f in sorted(SOURCES + HEADERS)}
 
 
+def generate(force: bool = False, verbose: bool = True) -> None:
+    for script, out in GENERATED:
+        sp, op = os.path.join(CSRC, script), os.path.join(CSRC, out)
+        if force or _stale(op, [sp]):
+            if verbose:
+                print('[build] generating', out, flush=True)
+            subprocess.run([sys.executable, sp], check=True)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
+    generate(force, verbose)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for src in SOURCES:

@@ -946,6 +946,84 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
   }
 }
 
+// The same algorithm as ONE hand-placed instruction stream (gen_attn_bwd_sp.py -> attn_bwd_sp_body.inc; register map, schedule and the
+// hazard rules are documented there).  This wrapper computes the per-lane LDS / global offsets and the scalar state, stages K and the
+// first two query tiles, and hands everything to the generated asm statement, which owns v[0:223] and a[0:255].  q must be prescaled
+// (base-2 logits straight from the MFMAs: no multiply per element).
+constexpr int SPX_SLOT = 16384 + 1024;
+constexpr int SPX_DS = 65536;
+constexpr int SPX_LDS = SPX_DS + 2 * 32768;
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ki = lane & 31, hh = lane >> 5;
+  int bh, kblk;
+  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, kblk);
+  const int b = bh / a.H, h = bh % a.H;
+  const int HD2 = a.H * 64 * 2;                    // bytes per slab row
+
+  const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
+  const u32x4 rdo = make_srd(a.d_o + b * a.do_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
+  const u32x4 rk = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const u32x4 rdk = make_srd(a.dk + b * a.dk_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dk_rs + 64) * 2));
+  const u32x4 rdv = make_srd(a.dv + b * a.dv_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dv_rs + 64) * 2));
+  const u32x4 rslab = make_srd(slabs + (int64_t)kblk * slab_stride + (int64_t)b * a.Nq * (a.H * 64), (uint32_t)((int64_t)a.Nq * HD2));
+  const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
+  // row constants: wave 1 fetches -delta, the others -lse/scale (waves 2 / 3 into spare vectors of the slot: every wave issues the same five pieces)
+  const float* rcp = wave == 1 ? a.delta + ((int64_t)b * a.H + h) * a.Nq : a.delta + nrows + ((int64_t)b * a.H + h) * a.Nq;
+  const u32x4 rrc = make_srd(rcp, (uint32_t)a.Nq * 4u);
+  const uint32_t sbase = lds_addr_of(smem);
+  const LaneAddr la = make_lane_addr(lane);
+  const int key_wg = kblk * 256, key0 = key_wg + wave * 64;
+  const int qh = wave >> 1, dbq = wave & 1;        // dQ phase: this wave's block = d rows 32 dbq.., q columns 32 qh..
+
+  uint32_t arow0 = sbase + la.row[0], arow1 = sbase + la.row[1], arow2 = sbase + la.row[2], arow3 = sbase + la.row[3];
+  uint32_t atr0 = sbase + la.tr[0][0], atr1 = sbase + la.tr[0][1], atr2 = sbase + la.tr[1][0], atr3 = sbase + la.tr[1][1];
+  uint32_t aseed = sbase + 16384 + 16 * hh;
+  const uint32_t dsw = sbase + SPX_DS + wave * 8192 + ki * 128 + 8 * hh;
+  const int sw = swz64(ki);
+  uint32_t adsw0 = dsw + ((0 ^ sw) << 4), adsw1 = dsw + ((1 ^ sw) << 4), adsw2 = dsw + ((2 ^ sw) << 4), adsw3 = dsw + ((3 ^ sw) << 4),
+           adsw4 = dsw + ((4 ^ sw) << 4), adsw5 = dsw + ((5 ^ sw) << 4), adsw6 = dsw + ((6 ^ sw) << 4), adsw7 = dsw + ((7 ^ sw) << 4);
+  uint32_t atrs0 = sbase + SPX_DS + 32768 + (qh ? la.tr[1][0] : la.tr[0][0]), atrs1 = sbase + SPX_DS + 32768 + (qh ? la.tr[1][1] : la.tr[0][1]);
+  uint32_t atrk0 = sbase + SPX_DS + (dbq ? la.tr[1][0] : la.tr[0][0]), atrk1 = sbase + SPX_DS + (dbq ? la.tr[1][1] : la.tr[0][1]);
+  const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
+  uint32_t sqv = sq.v, sdov = sdo.v, rcv = (uint32_t)lane * 4u;
+  uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2);
+  uint32_t dkv = (uint32_t)(((int64_t)(key0 + ki) * a.dk_rs + 4 * hh) * 2), dvv = (uint32_t)(((int64_t)(key0 + ki) * a.dv_rs + 4 * hh) * 2);
+  const int kr0 = min(key0 + ki, a.Nk - 1), kr1 = min(key0 + 32 + ki, a.Nk - 1);
+  uint32_t koff0 = (uint32_t)(((int64_t)kr0 * a.k_rs + 8 * hh) * 2), koff1 = (uint32_t)(((int64_t)kr1 * a.k_rs + 8 * hh) * 2);
+  uint32_t voff0 = (uint32_t)(((int64_t)kr0 * a.v_rs + 8 * hh) * 2), voff1 = (uint32_t)(((int64_t)kr1 * a.v_rs + 8 * hh) * 2);
+
+  const int nqt64 = (a.Nq + 63) / 64;
+  const uint32_t s_qstep = (uint32_t)(64 * a.q_rs * 2), s_dostep = (uint32_t)(64 * a.do_rs * 2);
+  const uint32_t s_q32 = (uint32_t)(32 * a.q_rs * 2), s_do32 = (uint32_t)(32 * a.do_rs * 2);
+  const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
+  const float s_dkscale = a.scale;
+  const uint32_t s_iters = (uint32_t)nqt64 + 1u;   // the last pass only finishes dQ of the last tile (its other products see zero rows)
+  const uint32_t s_S = SPX_SLOT, s_m2S = (uint32_t)(-2 * SPX_SLOT);
+  // running state: the DMA of pass t fetches tile t + 2; the slab offset advances before the stores of a pass (tile t - 1)
+  uint32_t s_qoff = 2u * s_qstep, s_dooff = 2u * s_dostep, s_rcoff = 2u * 256u, s_slaboff = (uint32_t)(-2 * (int)s_slabstep);
+  uint32_t s_m0q = sbase + 2 * SPX_SLOT + wave * 1024, s_m0rc = sbase + 2 * SPX_SLOT + 16384 + wave * 256;
+  uint32_t s_cD = 2, s_cA = 1, s_cB = 1, s_dA = SPX_SLOT, s_dB = SPX_SLOT;
+  uint32_t s_tmp0, s_tmp1, s_cnt;
+
+  // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: whatever dS the clamped fragments of such keys produce, it meets a
+  // zero K^T row in dQ), query tiles 0 and 1 -> ring slots 0 and 1
+#pragma unroll
+  for (int j = 0; j < 4; ++j) stage64(rk, sbase + SPX_DS + j * 8192, sk, key_wg + 64 * j, a.k_rs, wave);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t base = sbase + t * SPX_SLOT;
+    stage64(rq, base, sq, t * 64, a.q_rs, wave);
+    stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
+    dma4(rrc, base + 16384 + wave * 256, rcv, (uint32_t)t * 256u);
+  }
+#include "attn_bwd_sp_body.inc"
+}
+
 // dq[b, q, h*64 + d] = bf16(scale * sum over slabs (fp32, in slab order) of slab[s][b][q][h*64 + d]); 16 bytes per thread and slab
 __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const u16* __restrict__ slabs, int64_t slab_stride, int nslab, u16* __restrict__ dq,
                                                              int64_t dq_bs, int64_t dq_rs, int B, int Nq, int HD, float scale) {
@@ -1044,12 +1122,12 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
 static int g_bwd_parts = 7;
 static int g_bwd_mode = 0;      // 0 auto (= two-pass: the faster form on gfx950, see the fused kernel's header), 1 two-pass, 2 fused single pass whenever legal
 extern "C" int crl_attn_bwd_set_mode(int mode) {
-  if (mode < 0 || mode > 2) { crl_set_error("crl_attn_bwd_set_mode: 0 auto, 1 two-pass, 2 fused"); return -1; }
+  if (mode < 0 || mode > 3) { crl_set_error("crl_attn_bwd_set_mode: 0 auto, 1 two-pass, 2 single pass, 3 single pass (C++ reference form)"); return -1; }
   g_bwd_mode = mode;
   return 0;
 }
 static bool bwd_fused_wanted(int Nq, int Nk, int causal) {
-  return !causal && g_bwd_mode == 2 && g_bwd_parts == 7;
+  return !causal && g_bwd_mode >= 2 && g_bwd_parts == 7;
 }
 // bf16 partial-dQ slabs of the fused backward: ceil(Nk / 256) x [B, Nq, H * 64]; 0 = the two-pass form runs (no workspace needed)
 extern "C" size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal) {
@@ -1114,8 +1192,9 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     CRL_CHECK(((uintptr_t)ws % 16) == 0 && (dq_rs % 8) == 0, "%s: workspace / dq must be 16-byte aligned", who);
     static bool configured = false;
     if (!configured) {
-      for (const void* f : {reinterpret_cast<const void*>(&attn_bwd_sp_kernel<false>), reinterpret_cast<const void*>(&attn_bwd_sp_kernel<true>)}) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+      for (const void* f : {reinterpret_cast<const void*>(&attn_bwd_sp_kernel<false>), reinterpret_cast<const void*>(&attn_bwd_sp_kernel<true>),
+                            reinterpret_cast<const void*>(&attn_bwd_spx_kernel)}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, f == reinterpret_cast<const void*>(&attn_bwd_spx_kernel) ? SPX_LDS : SP_LDS);
         if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, SP_LDS, hipGetErrorString(e)); return -2; }
       }
       configured = true;
@@ -1128,7 +1207,8 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     const int64_t slab_stride = (int64_t)B * Nq * H * 64;
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
-    if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
+    if (q_prescaled && g_bwd_mode != 3) attn_bwd_spx_kernel<<<(unsigned)a.nkt * B * H, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride);
+    else if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
     else attn_bwd_sp_kernel<false><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
     CRL_PROF_STOP(CRL_K_ATTN_BWD_FUSED, stream);
     CRL_LAUNCH_CHECK("crl_attn_bwd(fused)");

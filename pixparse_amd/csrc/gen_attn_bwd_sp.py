@@ -1,0 +1,533 @@
+#!/usr/bin/env python3
+"""Generates attn_bwd_sp_body.inc: the hand-placed gfx950 instruction stream of the single-pass attention backward
+(attention.hip: attn_bwd_sp_kernel).  One workgroup = 4 waves = 256 keys of one (batch, head), one wave per SIMD with the whole
+512-entry register file; the stream is ONE inline-asm statement whose registers are allocated here:
+
+  a[0:63]     dV^T accumulators  [kb][db] x 16        a[64:127]   dK^T accumulators
+  a[128:159]  K row fragments    [kb][ks] x 4         a[160:191]  V row fragments
+  a[192:255]  K^T fragments of the workgroup's 256 keys for this wave's dQ block  [16] x 4
+  v[0:63]     S / dP accumulators, two sets (one per key block kb)
+  v[64:95]    P / dS as bf16 MFMA operands, two sets
+  v[96:127]   row constants (-lse log2e, -delta) of the current 32-query block: the C operand of the first MFMA of every S / dP chain
+  v[128:159]  Q / dO row fragments of the current 32-query block (each feeds both key blocks)
+  v[160:191]  Q^T / dO^T transposed fragments of the current 32-query block (each feeds both key blocks)
+  v[192:207]  dS^T fragments for the dQ product       v[208:223]  dQ^T accumulator
+  v[224:255]  left to the compiler: the per-lane LDS / global offsets it passes in as operands
+
+Per 64-query tile a wave issues 80 MFMAs (32 S / dP, 32 dV / dK, 16 dQ of the PREVIOUS tile) as a fixed backbone; everything else --
+112 LDS instructions, 64 v_exp, 64 multiplies, 72 conversions, 5 LDS-DMA pieces, 4 slab stores, address updates, counted waits -- is
+assigned to one of the 80 MFMA gaps by the tables below.  Software pipeline over 32 x 32 blocks n = (qb, kb):
+  slot n:  MFMAs  S / dP of block n + 1  |  dV / dK of block n - 1  |  a quarter of dQ(t - 1)     VALU: exp / mul / cvt of block n
+so no MFMA ever waits for VALU work of its own slot.  One s_barrier per tile (top of the iteration): dS of tile t - 1 complete, ring
+slot of tile t - 1 and dS buffer of tile t - 2 free.  Q / dO tiles arrive by LDS-DMA two tiles ahead (ring of 3).
+
+The hazard pass below inserts what hipcc does not do for asm: counted s_waitcnt lgkmcnt for every LDS read before its first consumer,
+s_nop between a VALU write and an MFMA read of the same register, and it CHECKS (does not fix) the MFMA-result -> VALU distance.
+"""
+import os
+import sys
+
+# ----------------------------------------------------------------------------------------------- registers
+A_DV, A_DK, A_KF, A_VF, A_KA = 0, 64, 128, 160, 192
+V_S = [0, 32]
+V_D = [16, 48]
+V_P = [64, 80]
+V_DS = [72, 88]
+V_SEEDL, V_SEEDD = 96, 112
+V_QF, V_DOF = 128, 144
+V_TF = 160
+V_DSF = 192
+V_DQ = 208
+N_HAND = 224
+
+SLOT = 16384 + 1024            # ring slot: Q tile | dO tile | 4 x 256 B row-constant vectors (waves 0 / 1: -lse', -delta; 2 / 3: unused copies)
+RING = 3
+DS_BASE = 65536                # two dS buffers of 32 KiB: 65536, 98304 (toggle = xor 0x8000); K is staged through the first one
+LDS_BYTES = DS_BASE + 2 * 32768
+
+
+def vr(b, n=1):
+    return f'v{b}' if n == 1 else f'v[{b}:{b + n - 1}]'
+
+
+def ar(b, n=1):
+    return f'a{b}' if n == 1 else f'a[{b}:{b + n - 1}]'
+
+
+def regs(prefix, b, n):
+    return [f'{prefix}{i}' for i in range(b, b + n)]
+
+
+class I:
+    """one instruction: text + what the hazard pass needs"""
+    def __init__(self, text, kind, reads=(), writes=(), cost=4):
+        self.text, self.kind, self.reads, self.writes, self.cost = text, kind, tuple(reads), tuple(writes), cost
+
+    def __repr__(self):
+        return self.text
+
+
+def op(name):
+    return f'%[{name}]'
+
+
+# ----------------------------------------------------------------------------------------------- instruction builders
+def mfma(d, a, b, c, dn, an, bn, cn):
+    """d/a/b/c: (prefix, base); dn.. register counts; c may be the string '0'"""
+    ds_ = (ar if d[0] == 'a' else vr)(d[1], 16)
+    as_ = (ar if a[0] == 'a' else vr)(a[1], 4)
+    bs_ = (ar if b[0] == 'a' else vr)(b[1], 4)
+    if c == '0':
+        cs, cr = '0', []
+    else:
+        cs, cr = (ar if c[0] == 'a' else vr)(c[1], 16), regs(c[0], c[1], 16)
+    return I(f'v_mfma_f32_32x32x16_bf16 {ds_}, {as_}, {bs_}, {cs}', 'mfma',
+             reads=regs(a[0], a[1], 4) + regs(b[0], b[1], 4) + cr, writes=regs(d[0], d[1], 16), cost=8)
+
+
+def ds_read_b128(dst, addr_op, off):
+    return I(f'ds_read_b128 {vr(dst, 4)}, {op(addr_op)} offset:{off}', 'ds', reads=[addr_op], writes=regs('v', dst, 4))
+
+
+def ds_read_tr(dst_prefix, dst, addr_op, off):
+    d = (ar if dst_prefix == 'a' else vr)(dst, 2)
+    return I(f'ds_read_b64_tr_b16 {d}, {op(addr_op)} offset:{off}', 'ds', reads=[addr_op], writes=regs(dst_prefix, dst, 2))
+
+
+def ds_write_b64(addr_op, src, off):
+    return I(f'ds_write_b64 {op(addr_op)}, {vr(src, 2)} offset:{off}', 'ds', reads=[addr_op] + regs('v', src, 2))
+
+
+def valu(text, reads, writes, cost=4, kind='valu'):
+    return I(text, kind, reads=reads, writes=writes, cost=cost)
+
+
+def v_exp(r):
+    return valu(f'v_exp_f32 v{r}, v{r}', [f'v{r}'], [f'v{r}'], cost=8, kind='trans')
+
+
+def v_mul(d, a, b):
+    return valu(f'v_mul_f32 v{d}, v{a}, v{b}', [f'v{a}', f'v{b}'], [f'v{d}'])
+
+
+def v_cvt(d, a, b):
+    return valu(f'v_cvt_pk_bf16_f32 v{d}, v{a}, v{b}', [f'v{a}', f'v{b}'], [f'v{d}'])
+
+
+def salu(text):
+    return I(text, 'salu')
+
+
+# ----------------------------------------------------------------------------------------------- the pieces of a tile
+def m1_block(qb_unused, kb, first_c_seed=True):
+    """S / dP of one 32 x 32 block into accumulator set kb: 8 MFMAs (Q / dO row fragments x K / V row fragments of key block kb)"""
+    out = []
+    for ks in range(4):
+        cS = ('v', V_SEEDL) if ks == 0 else ('v', V_S[kb])
+        cD = ('v', V_SEEDD) if ks == 0 else ('v', V_D[kb])
+        out.append(mfma(('v', V_S[kb]), ('v', V_QF + 4 * ks), ('a', A_KF + 4 * (4 * kb + ks)), cS, 16, 4, 4, 16))
+        out.append(mfma(('v', V_D[kb]), ('v', V_DOF + 4 * ks), ('a', A_VF + 4 * (4 * kb + ks)), cD, 16, 4, 4, 16))
+    return out
+
+
+def tf(ss, f):
+    """transposed fragment register base: f = 0 dO^T d-block 0, 1 dO^T d-block 1, 2 Q^T d-block 0, 3 Q^T d-block 1"""
+    return V_TF + 16 * ss + 4 * f
+
+
+def m2_block(kb):
+    """dV^T / dK^T of key block kb += (dO^T | Q^T) . (P | dS): 8 MFMAs"""
+    out = []
+    for ss in range(2):
+        p, d = V_P[kb] + 4 * ss, V_DS[kb] + 4 * ss
+        for db in range(2):
+            acc = A_DV + 16 * (2 * kb + db)
+            out.append(mfma(('a', acc), ('v', tf(ss, db)), ('v', p), ('a', acc), 16, 4, 4, 16))
+        for db in range(2):
+            acc = A_DK + 16 * (2 * kb + db)
+            out.append(mfma(('a', acc), ('v', tf(ss, 2 + db)), ('v', d), ('a', acc), 16, 4, 4, 16))
+    return out
+
+
+def dq_quarter(w):
+    out = []
+    for kk in range(4):
+        c = '0' if (w == 0 and kk == 0) else ('v', V_DQ)
+        out.append(mfma(('v', V_DQ), ('a', A_KA + 4 * (4 * w + kk)), ('v', V_DSF + 4 * kk), c, 16, 4, 4, 16))
+    return out
+
+
+def valu_block(qb, kb):
+    """exp / mul / cvt of block (qb, kb) and the four dS stores; returns dict name -> list of instructions in dependency order"""
+    S, D, P, DS = V_S[kb], V_D[kb], V_P[kb], V_DS[kb]
+    ex = [v_exp(S + r) for r in range(16)]
+    mu = [v_mul(D + r, S + r, D + r) for r in range(16)]
+    cp = [v_cvt(P + j, S + 2 * j, S + 2 * j + 1) for j in range(8)]
+    cd = [v_cvt(DS + j, D + 2 * j, D + 2 * j + 1) for j in range(8)]
+    wr = []
+    for ss in range(2):
+        c0 = 4 * qb + 2 * ss
+        wr.append(ds_write_b64(f'adsw{c0}', DS + 4 * ss, 4096 * kb))
+        wr.append(ds_write_b64(f'adsw{c0 + 1}', DS + 4 * ss + 2, 4096 * kb))
+    return dict(exp=ex, mul=mu, cvtp=cp, cvtd=cd, wr=wr)
+
+
+def load_seeds(qb):
+    out = []
+    for g in range(4):
+        out.append(ds_read_b128(V_SEEDL + 4 * g, 'aseed', 128 * qb + 32 * g))
+        out.append(ds_read_b128(V_SEEDD + 4 * g, 'aseed', 256 + 128 * qb + 32 * g))
+    return out
+
+
+def load_qf(qb):
+    out = []
+    for ks in range(4):
+        out.append(ds_read_b128(V_QF + 4 * ks, f'arow{ks}', 4096 * qb))
+        out.append(ds_read_b128(V_DOF + 4 * ks, f'arow{ks}', 8192 + 4096 * qb))
+    return out
+
+
+def load_tf(qb, ss):
+    out = []
+    off = (32 * qb + 16 * ss) * 128
+    for f in range(4):
+        db, tile = f & 1, (8192 if f < 2 else 0)
+        out.append(ds_read_tr('v', tf(ss, f), f'atr{2 * db}', tile + off))
+        out.append(ds_read_tr('v', tf(ss, f) + 2, f'atr{2 * db + 1}', tile + off))
+    return out
+
+
+def load_dsf(w):
+    out = []
+    for kk in range(4):
+        out.append(ds_read_tr('v', V_DSF + 4 * kk, 'atrs0', w * 8192 + kk * 2048))
+        out.append(ds_read_tr('v', V_DSF + 4 * kk + 2, 'atrs1', w * 8192 + kk * 2048))
+    return out
+
+
+def dq_store():
+    """dQ^T block -> bf16 in place -> four 8-byte stores into the slab (rows past Nq, and the whole tile -1, fall off the descriptor)"""
+    cv, st = [], []
+    for g in range(4):
+        b = V_DQ + 4 * g
+        cv.append(v_cvt(b, b, b + 1))
+        cv.append(v_cvt(b + 1, b + 2, b + 3))
+        st.append(I(f'buffer_store_dwordx2 {vr(b, 2)}, {op("slabv")}, {op("rslab")}, {op("s_slaboff")} offen offset:{16 * g}', 'vmem',
+                    reads=regs('v', b, 2) + ['slabv']))
+    return cv, st
+
+
+def dma_tile():
+    """the five LDS-DMA pieces of one wave for tile t + 2: two of Q, two of dO, one row-constant vector"""
+    out = []
+    def piece(m0expr_setup, srd, voff, soff, width):
+        ins = list(m0expr_setup)
+        ins.append(I(f's_nop 0\n\tbuffer_load_{width} {op(voff)}, {op(srd)}, {soff} offen lds', 'vmem', reads=[voff], cost=12))
+        return ins
+    out += piece([salu(f's_mov_b32 m0, {op("s_m0q")}')], 'rq', 'sqv', op('s_qoff'), 'dwordx4')
+    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 4096'), salu(f's_add_u32 {op("s_tmp1")}, {op("s_qoff")}, {op("s_q32")}'),
+                  salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rq', 'sqv', op('s_tmp1'), 'dwordx4')
+    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 8192'), salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rdo', 'sdov', op('s_dooff'), 'dwordx4')
+    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 12288'), salu(f's_add_u32 {op("s_tmp1")}, {op("s_dooff")}, {op("s_do32")}'),
+                  salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rdo', 'sdov', op('s_tmp1'), 'dwordx4')
+    out += piece([salu(f's_mov_b32 m0, {op("s_m0rc")}')], 'rrc', 'rcv', op('s_rcoff'), 'dword')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- placement
+class Gaps:
+    def __init__(self, n):
+        self.g = [[] for _ in range(n)]
+
+    def put(self, gap, ins):
+        self.g[gap].append(ins)
+
+    def spread(self, lo, hi, inss, per_gap=None):
+        """instructions in order, evenly over gaps lo..hi (inclusive)"""
+        n = len(inss)
+        if n == 0:
+            return
+        width = hi - lo + 1
+        for j, ins in enumerate(inss):
+            self.g[lo + (j * width) // n].append(ins)
+
+    def cost(self, gap):
+        return sum(i.cost for i in self.g[gap])
+
+
+def build_iteration():
+    """returns (backbone: 80 MFMAs, gaps: 80 lists of fillers).  gap i = the instructions issued right after MFMA i"""
+    bb = []
+    G = Gaps(80)
+    for s in range(4):
+        qb, kb = s >> 1, s & 1
+        g0 = 20 * s
+        nkb = 1 - kb                                  # key block of the next block (= accumulator set it uses)
+        m1 = m1_block(None, nkb)
+        m2 = m2_block(nkb)                            # previous block has the other kb as well
+        dq = dq_quarter(s)
+        if s == 3:
+            bb += m1 + dq + m2                        # the last quarter of dQ early: its conversion + stores fit behind it in this slot
+        else:
+            bb += m1 + m2 + dq
+        # ---- VALU of block (qb, kb): exp r in gap r, mul one gap later, conversions trailing
+        vb = valu_block(qb, kb)
+        for r in range(16):
+            G.put(g0 + r, vb['exp'][r])
+            G.put(g0 + r + 1, vb['mul'][r])
+        for j in range(8):
+            G.put(g0 + 2 * j + 3, vb['cvtp'][j])
+            G.put(g0 + 2 * j + 4, vb['cvtd'][j])
+        G.put(g0 + 11, vb['wr'][0]); G.put(g0 + 12, vb['wr'][1])
+        G.put(g0 + 19, vb['wr'][2]); G.put(g0 + 19, vb['wr'][3])
+        # ---- dS^T fragments of this slot's dQ quarter
+        if s == 3:
+            G.spread(g0 + 0, g0 + 6, load_dsf(s))     # used from MFMA 8 of the slot
+        else:
+            G.spread(g0 + 4, g0 + 11, load_dsf(s))    # used from MFMA 16
+        if kb == 0:
+            # row constants and row fragments of the NEXT 32-query block (this slot's M1 was the last user of the current ones)
+            nqb = 1 - qb
+            G.spread(g0 + 2, g0 + 9, load_seeds(nqb))
+            G.spread(g0 + 8, g0 + 15, load_qf(nqb))
+            # transposed fragments of THIS query block, first half (ss = 0: free once MFMA 11 of the slot has issued)
+            G.spread(g0 + 12, g0 + 19, load_tf(qb, 0))
+        else:
+            G.spread(g0 + 0, g0 + 6, load_tf(qb, 1))  # ss = 1 (free since MFMA 15 of the previous slot); used from MFMA 12 / 16 of this slot
+    # ---- slot 1: LDS-DMA of tile t + 2 and the ring advance of the row-fragment / row-constant addresses (tile t -> t + 1)
+    g0 = 20
+    dma = dma_tile()
+    G.spread(g0 + 7, g0 + 16, dma)
+    for k, name in enumerate(['arow0', 'arow1', 'arow2', 'arow3', 'aseed']):
+        G.put(g0 + 14 + k, valu(f'v_add_u32 {op(name)}, {op("s_dA")}, {op(name)}', [name], [name]))
+    # ---- slot 3: dQ conversion + stores (dQ MFMAs are 8..11 of the slot), address toggles, ring advance of the transposed addresses
+    g0 = 60
+    cv, st = dq_store()
+    G.spread(g0 + 14, g0 + 17, cv)
+    for k in range(4):
+        G.put(g0 + 18 + (k >> 1), st[k])
+    for k in range(4):
+        G.put(g0 + 8 + k, valu(f'v_add_u32 {op(f"atr{k}")}, {op("s_dB")}, {op(f"atr{k}")}', [f'atr{k}'], [f'atr{k}']))
+    for k in range(2):
+        G.put(g0 + 12 + k, valu(f'v_xor_b32 {op(f"atrs{k}")}, 0x8000, {op(f"atrs{k}")}', [f'atrs{k}'], [f'atrs{k}']))
+    return bb, G
+
+
+def scalar_tail():
+    """per-iteration scalar bookkeeping, placed in the last gaps of the iteration (after the last LDS write / store that uses them)"""
+    S = SLOT
+    t = []
+    # running DMA source offsets and slab offset
+    t.append(salu(f's_add_u32 {op("s_qoff")}, {op("s_qoff")}, {op("s_qstep")}'))
+    t.append(salu(f's_add_u32 {op("s_dooff")}, {op("s_dooff")}, {op("s_dostep")}'))
+    t.append(salu(f's_add_u32 {op("s_rcoff")}, {op("s_rcoff")}, 256'))
+    # ring positions: DMA destination slot (tile t + 2), row-fragment addresses (tile t + 1 -> t + 2), transposed addresses (t -> t + 1)
+    # each is a counter 0..2; the address delta is +S, or -2S when the counter wraps
+    for cnt, m0s, delta in (('s_cD', ('s_m0q', 's_m0rc'), None), ('s_cA', (), 's_dA'), ('s_cB', (), 's_dB')):
+        t.append(salu(f's_add_u32 {op(cnt)}, {op(cnt)}, 1'))
+        t.append(salu(f's_cmp_eq_u32 {op(cnt)}, 3'))
+        t.append(salu(f's_cselect_b32 {op(cnt)}, 0, {op(cnt)}'))
+        t.append(salu(f's_cselect_b32 {op("s_tmp0")}, {op("s_m2S")}, {op("s_S")}'))
+        if delta:
+            t.append(salu(f's_mov_b32 {op(delta)}, {op("s_tmp0")}'))
+        for m in m0s:
+            t.append(salu(f's_add_u32 {op(m)}, {op(m)}, {op("s_tmp0")}'))
+    return t
+
+
+# ----------------------------------------------------------------------------------------------- hazard / wait pass
+class Hazards:
+    """walks a linear stream; inserts counted lgkmcnt waits and VALU->MFMA nops; checks MFMA->VALU distance"""
+    def __init__(self):
+        self.pending = []          # outstanding DS ops in issue order: (serial, set(written regs))
+        self.serial = 0
+        self.out = []
+        self.recent_valu = []      # [(age, written regs)] of the last VALU instructions
+        self.mfma_written = {}     # reg -> index (in MFMA count) of the MFMA that last wrote it
+        self.n_mfma = 0
+        self.last_trans = None     # registers written by the directly preceding transcendental
+
+    def emit(self, ins):
+        used = set(ins.reads) | set(ins.writes)
+        # ---- LDS results: wait for the youngest pending read that touches a used register
+        need = None
+        for k, (ser, wr) in enumerate(self.pending):
+            if wr & used:
+                need = k
+        if need is not None:
+            outstanding_after = len(self.pending) - 1 - need
+            self.out.append(I(f's_waitcnt lgkmcnt({min(outstanding_after, 15)})', 'wait'))
+            self.pending = self.pending[need + 1:] if outstanding_after <= 15 else []
+            self.recent_valu = []          # a wait is an instruction between the VALU and the consumer
+            self.last_trans = None
+        # ---- VALU result -> MFMA operand: two wait states
+        if ins.kind == 'mfma':
+            hazard = 0
+            for age, wr in self.recent_valu:
+                if wr & set(ins.reads):
+                    hazard = max(hazard, 3 - age)
+            if hazard > 0:
+                self.out.append(I(f's_nop {hazard - 1}', 'nop'))
+                self.recent_valu = [(a + hazard, w) for a, w in self.recent_valu]
+        # ---- MFMA result -> VALU / LDS / store reading it: needs the MFMA (8 passes) finished; two later MFMAs guarantee that
+        if ins.kind in ('valu', 'trans', 'ds', 'vmem'):
+            for r in ins.reads:
+                if r in self.mfma_written and self.n_mfma - self.mfma_written[r] < 3:
+                    raise RuntimeError(f'MFMA result {r} read too early by: {ins.text}')
+            for r in ins.writes:
+                if r in self.mfma_written and self.n_mfma - self.mfma_written[r] < 3 and ins.kind != 'ds':
+                    raise RuntimeError(f'MFMA result {r} overwritten too early by: {ins.text}')
+        # ---- transcendental result -> next VALU: one wait state (gfx940+ VALUTransUseHazard)
+        if self.last_trans and ins.kind in ('valu', 'trans') and (self.last_trans & set(ins.reads)):
+            self.out.append(I('s_nop 0', 'nop'))
+        self.out.append(ins)
+        # ---- bookkeeping
+        self.recent_valu = [(a + 1, w) for a, w in self.recent_valu if a + 1 < 3]
+        if ins.kind in ('valu', 'trans'):
+            self.recent_valu.append((0, set(ins.writes)))
+        self.last_trans = set(ins.writes) if ins.kind == 'trans' else None
+        if ins.kind == 'ds':
+            self.serial += 1
+            self.pending.append((self.serial, set(ins.writes)))
+        if ins.kind == 'mfma':
+            self.n_mfma += 1
+            for r in ins.writes:
+                self.mfma_written[r] = self.n_mfma
+            for r in ins.writes:
+                pass
+
+    def drain(self, text):
+        """an explicit full wait (lgkmcnt(0) inside `text`) resets the LDS bookkeeping"""
+        self.out.append(I(text, 'wait'))
+        self.pending = []
+        self.recent_valu = []
+        self.last_trans = None
+
+    def settle_mfma(self):
+        self.mfma_written = {}
+
+
+# ----------------------------------------------------------------------------------------------- whole statement
+VOPS = ['arow0', 'arow1', 'arow2', 'arow3', 'atr0', 'atr1', 'atr2', 'atr3', 'aseed'] + [f'adsw{i}' for i in range(8)] + \
+       ['atrs0', 'atrs1', 'sqv', 'sdov', 'rcv', 'slabv', 'dkv', 'dvv', 'atrk0', 'atrk1', 'koff0', 'koff1', 'voff0', 'voff1']
+SRDS = ['rq', 'rdo', 'rrc', 'rk', 'rv', 'rdk', 'rdv', 'rslab']
+SIN = ['s_qstep', 's_dostep', 's_q32', 's_do32', 's_slabstep', 's_dk32', 's_dv32', 's_dkscale', 's_iters', 's_S', 's_m2S']
+SRW = ['s_qoff', 's_dooff', 's_rcoff', 's_slaboff', 's_m0q', 's_m0rc', 's_cD', 's_cA', 's_cB', 's_dA', 's_dB']
+STMP = ['s_tmp0', 's_tmp1', 's_cnt']
+
+
+def generate():
+    H = Hazards()
+    E = H.emit
+    # ================================================================= prologue
+    for i in range(128):
+        E(valu(f'v_accvgpr_write_b32 a{i}, 0', [], [f'a{i}']))
+    for b in (V_P[0], V_P[1]):
+        for i in range(16):
+            E(valu(f'v_mov_b32 v{b + i}, 0', [], [f'v{b + i}']))
+    for i in range(32):
+        E(valu(f'v_mov_b32 v{V_TF + i}, 0', [], [f'v{V_TF + i}']))
+    for i in range(16):
+        E(valu(f'v_mov_b32 v{V_DSF + i}, 0', [], [f'v{V_DSF + i}']))
+    # K / V row fragments of this wave's 64 keys straight into the accumulator file (rows past Nk are clamped to the last key)
+    for kb in range(2):
+        for ks in range(4):
+            E(I(f'buffer_load_dwordx4 {ar(A_KF + 4 * (4 * kb + ks), 4)}, {op(f"koff{kb}")}, {op("rk")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'koff{kb}']))
+            E(I(f'buffer_load_dwordx4 {ar(A_VF + 4 * (4 * kb + ks), 4)}, {op(f"voff{kb}")}, {op("rv")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'voff{kb}']))
+    H.drain('s_waitcnt vmcnt(0)')        # K staging, tiles 0 and 1 (issued by the C++ part), the fragments above
+    E(I('s_barrier', 'barrier'))
+    # K^T fragments [32 d of this wave's d block][256 keys] from the staged K tiles
+    for kk in range(16):
+        off = (kk >> 2) * 8192 + (kk & 3) * 2048
+        E(ds_read_tr('a', A_KA + 4 * kk, 'atrk0', off))
+        E(ds_read_tr('a', A_KA + 4 * kk + 2, 'atrk1', off))
+    for ins in load_seeds(0) + load_qf(0):
+        E(ins)
+    H.drain('s_waitcnt lgkmcnt(0)')
+    for m in m1_block(None, 0):          # S / dP of block (tile 0, qb 0, kb 0)
+        E(m)
+    E(I('s_nop 7\n\ts_nop 7', 'nop'))
+    H.settle_mfma()
+    E(salu(f's_mov_b32 {op("s_cnt")}, {op("s_iters")}'))
+    # ================================================================= loop
+    bb, G = build_iteration()
+    tail = scalar_tail()
+    # scalar tail + dS write-address toggle in the last gaps
+    for k, ins in enumerate(tail):
+        G.put(72 + (k * 7) // len(tail), ins)
+    # the slab offset advances BEFORE this iteration's stores (they come in the last gaps): it starts two tiles back
+    G.put(1, salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
+    H.out.append(I('LOOP%=:', 'label'))
+    # top of the iteration: tile t + 1 landed (the four slab stores of the previous iteration may still be in flight), this wave's dS
+    # stores and every LDS read of the previous iteration are complete
+    H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
+    E(I('s_barrier', 'barrier'))
+    # the loop body starts from a settled matrix pipe only on the first pass; the distances are checked as if it were not
+    for i, m in enumerate(bb):
+        E(m)
+        for ins in G.g[i]:
+            E(ins)
+    # dS write addresses: toggle the buffer (every write of this tile has been issued)
+    for c0 in range(8):
+        E(valu(f'v_xor_b32 {op(f"adsw{c0}")}, 0x8000, {op(f"adsw{c0}")}', [f'adsw{c0}'], [f'adsw{c0}']))
+    E(salu(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1'))
+    E(salu(f's_cmp_lg_u32 {op("s_cnt")}, 0'))
+    E(I('s_cbranch_scc1 LOOP%=', 'branch'))
+    # ================================================================= epilogue: dK (scaled), dV -> bf16 -> bounds-checked stores
+    H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    E(I('s_nop 7\n\ts_nop 7', 'nop'))
+    H.settle_mfma()
+    tmp = 0
+    for which, abase, voff, srd, s32 in (('dk', A_DK, 'dkv', 'rdk', 's_dk32'), ('dv', A_DV, 'dvv', 'rdv', 's_dv32')):
+        for kb in range(2):
+            for db in range(2):
+                acc = abase + 16 * (2 * kb + db)
+                for g in range(4):
+                    r = tmp
+                    tmp = (tmp + 6) % 216
+                    for j in range(4):
+                        E(valu(f'v_accvgpr_read_b32 v{r + j}, a{acc + 4 * g + j}', [f'a{acc + 4 * g + j}'], [f'v{r + j}']))
+                    if which == 'dk':
+                        for j in range(4):
+                            E(valu(f'v_mul_f32 v{r + j}, {op("s_dkscale")}, v{r + j}', [f'v{r + j}'], [f'v{r + j}']))
+                    E(v_cvt(r + 4, r, r + 1))
+                    E(v_cvt(r + 5, r + 2, r + 3))
+                    soff = op(s32) if kb else '0'
+                    E(I(f'buffer_store_dwordx2 {vr(r + 4, 2)}, {op(voff)}, {op(srd)}, {soff} offen offset:{64 * db + 16 * g}', 'vmem', reads=regs('v', r + 4, 2)))
+    return H.out, G
+
+
+def render(stream):
+    lines = []
+    for ins in stream:
+        for ln in ins.text.split('\n\t'):
+            lines.append(ln)
+    body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
+    outs = ', '.join(f'[{n}] "+&v"({n})' for n in VOPS) + ',\n      ' + ', '.join(f'[{n}] "+&s"({n})' for n in SRW) + ',\n      ' + \
+        ', '.join(f'[{n}] "=&s"({n})' for n in STMP)
+    ins_ = ', '.join(f'[{n}] "s"({n})' for n in SRDS) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in SIN)
+    clob = ', '.join(f'"v{i}"' for i in range(N_HAND)) + ',\n      ' + ', '.join(f'"a{i}"' for i in range(256)) + ', "vcc", "scc", "memory"'
+    return ('// GENERATED by gen_attn_bwd_sp.py -- do not edit; see that file for the register map and the schedule\n'
+            'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
+
+
+def stats(stream, G):
+    kinds = {}
+    for ins in stream:
+        kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+    costs = [G.cost(i) for i in range(80)]
+    return kinds, costs
+
+
+if __name__ == '__main__':
+    stream, G = generate()
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, 'attn_bwd_sp_body.inc'), 'w') as f:
+        f.write(render(stream))
+    kinds, costs = stats(stream, G)
+    if '-v' in sys.argv:
+        print(kinds)
+        print('filler issue cycles per MFMA gap (budget 24):')
+        for s in range(4):
+            print('  slot', s, costs[20 * s:20 * s + 20])
