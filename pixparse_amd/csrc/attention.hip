@@ -954,6 +954,11 @@ constexpr int SPX_SLOT = 16384 + 1024;
 constexpr int SPX_DS = 65536;
 constexpr int SPX_LDS = SPX_DS + 2 * 32768;
 
+#ifdef SPX_STAMPS
+__device__ unsigned long long spx_dbg[2 * 4096];    // diagnostic build: (shader cycles, 100 MHz ticks) of the asm statement per workgroup
+constexpr int SPX_TR_WG = 64, SPX_TR_PASSES = 128;  // per-pass trace of the first 64 workgroups: [stamp k][workgroup][pass]; the others share a dump slot
+__device__ unsigned long long spx_trace[6 * (SPX_TR_WG + 1) * SPX_TR_PASSES];
+#endif
 __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1021,7 +1026,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
     stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
     dma4(rrc, base + 16384 + wave * 256, rcv, (uint32_t)t * 256u);
   }
+#ifdef SPX_STAMPS
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  uint32_t s_dbgoff = 0;
+  unsigned long long st0, st1, st2, st3, st4, st5;
+  const int trw = wave == 0 && blockIdx.x < SPX_TR_WG && nqt64 + 1 < SPX_TR_PASSES ? (int)blockIdx.x : SPX_TR_WG;
+  unsigned long long* const dbg0 = spx_trace + (0 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+  unsigned long long* const dbg1 = spx_trace + (1 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+  unsigned long long* const dbg2 = spx_trace + (2 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+  unsigned long long* const dbg3 = spx_trace + (3 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+  unsigned long long* const dbg4 = spx_trace + (4 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+  unsigned long long* const dbg5 = spx_trace + (5 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+#endif
 #include "attn_bwd_sp_body.inc"
+#ifdef SPX_STAMPS
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0 && blockIdx.x < 4096) { spx_dbg[2 * blockIdx.x] = c1 - c0; spx_dbg[2 * blockIdx.x + 1] = r1 - r0; }
+#endif
 }
 
 // dq[b, q, h*64 + d] = bf16(scale * sum over slabs (fp32, in slab order) of slab[s][b][q][h*64 + d]); 16 bytes per thread and slab
@@ -1249,6 +1270,15 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   else { if (int rc = run_dkdv()) return rc; if (int rc = run_dq()) return rc; }
   return 0;
 }
+
+#ifdef SPX_STAMPS
+extern "C" int crl_debug_spx_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(spx_dbg), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+extern "C" int crl_debug_spx_trace(unsigned long long* host) {      // 6 x 65 x 128
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(spx_trace), sizeof(spx_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // keep mask of the attention dropout as bytes [B, H, Nq, Nk] (1 = kept): lets the CPU oracle apply the very mask the kernels regenerate
 namespace {

@@ -336,6 +336,40 @@ def scalar_tail():
     return t
 
 
+# timing-only experiments (WRONG RESULTS): SPX_DROP=class,class,... removes instruction classes from the loop body
+#   exp mul cvt dsread dswrite dma store barrier addr salu
+DROP = set(filter(None, os.environ.get('SPX_DROP', '').split(',')))
+OPTS = dict(kv.split('=') if '=' in kv else (kv, '1') for kv in filter(None, os.environ.get('SPX_OPTS', '').split(',')))
+STAMPS = 'stamps' in OPTS     # diagnostic build (-DSPX_STAMPS): six s_memtime stamps per pass, written to a trace by scalar stores
+STAMP_AT = {19: 2, 39: 3, 59: 4}  # after MFMA n -> stamp k   (0: after the wait at the top, 1: after the barrier, 5: end of the pass)
+in_loop = [False]
+
+
+def drop_class(ins):
+    t = ins.text
+    if ins.kind == 'trans':
+        return 'exp'
+    if t.startswith('v_mul_f32'):
+        return 'mul'
+    if t.startswith('v_cvt_pk'):
+        return 'cvt'
+    if t.startswith('ds_read'):
+        return 'dsread'
+    if t.startswith('ds_write'):
+        return 'dswrite'
+    if 'lds' in t and 'buffer_load' in t:
+        return 'dma'
+    if t.startswith('buffer_store'):
+        return 'store'
+    if t.startswith('s_barrier'):
+        return 'barrier'
+    if t.startswith('v_add_u32') or t.startswith('v_xor_b32'):
+        return 'addr'
+    if ins.kind == 'salu' and 's_cnt' not in t and 'm0' not in t:
+        return 'salu'
+    return ins.kind
+
+
 # ----------------------------------------------------------------------------------------------- hazard / wait pass
 class Hazards:
     """walks a linear stream; inserts counted lgkmcnt waits and VALU->MFMA nops; checks MFMA->VALU distance"""
@@ -349,6 +383,8 @@ class Hazards:
         self.last_trans = None     # registers written by the directly preceding transcendental
 
     def emit(self, ins):
+        if DROP and in_loop[0] and drop_class(ins) in DROP:
+            return
         used = set(ins.reads) | set(ins.writes)
         # ---- LDS results: wait for the youngest pending read that touches a used register
         need = None
@@ -458,24 +494,40 @@ def generate():
         G.put(72 + (k * 7) // len(tail), ins)
     # the slab offset advances BEFORE this iteration's stores (they come in the last gaps): it starts two tiles back
     G.put(1, salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
+    if STAMPS:
+        H.out.append(I('\n\t'.join(f's_mov_b64 %[st{k}], 0' for k in range(6)), 'salu'))
     H.out.append(I('LOOP%=:', 'label'))
+    in_loop[0] = True
     # top of the iteration: tile t + 1 landed (the four slab stores of the previous iteration may still be in flight), this wave's dS
     # stores and every LDS read of the previous iteration are complete
     H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
+    if STAMPS:
+        # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
+        H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
+                       '\n\ts_add_u32 %[s_dbgoff], %[s_dbgoff], 8\n\ts_memtime %[st0]', 'salu'))
     E(I('s_barrier', 'barrier'))
+    if STAMPS:
+        H.out.append(I('s_memtime %[st1]', 'salu'))
     # the loop body starts from a settled matrix pipe only on the first pass; the distances are checked as if it were not
     for i, m in enumerate(bb):
         E(m)
         for ins in G.g[i]:
             E(ins)
+        if STAMPS and i in STAMP_AT:
+            H.out.append(I(f's_memtime %[st{STAMP_AT[i]}]', 'salu'))
     # dS write addresses: toggle the buffer (every write of this tile has been issued)
     for c0 in range(8):
         E(valu(f'v_xor_b32 {op(f"adsw{c0}")}, 0x8000, {op(f"adsw{c0}")}', [f'adsw{c0}'], [f'adsw{c0}']))
+    if STAMPS:
+        H.out.append(I('s_memtime %[st5]', 'salu'))
     E(salu(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1'))
     E(salu(f's_cmp_lg_u32 {op("s_cnt")}, 0'))
     E(I('s_cbranch_scc1 LOOP%=', 'branch'))
+    in_loop[0] = False
     # ================================================================= epilogue: dK (scaled), dV -> bf16 -> bounds-checked stores
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    if STAMPS:
+        H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) + '\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)', 'salu'))
     E(I('s_nop 7\n\ts_nop 7', 'nop'))
     H.settle_mfma()
     tmp = 0
@@ -504,9 +556,10 @@ def render(stream):
         for ln in ins.text.split('\n\t'):
             lines.append(ln)
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
-    outs = ', '.join(f'[{n}] "+&v"({n})' for n in VOPS) + ',\n      ' + ', '.join(f'[{n}] "+&s"({n})' for n in SRW) + ',\n      ' + \
-        ', '.join(f'[{n}] "=&s"({n})' for n in STMP)
-    ins_ = ', '.join(f'[{n}] "s"({n})' for n in SRDS) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in SIN)
+    srw = SRW + (['s_dbgoff'] if STAMPS else [])
+    outs = ', '.join(f'[{n}] "+&v"({n})' for n in VOPS) + ',\n      ' + ', '.join(f'[{n}] "+&s"({n})' for n in srw) + ',\n      ' + \
+        ', '.join(f'[{n}] "=&s"({n})' for n in STMP + ([f'st{k}' for k in range(6)] if STAMPS else []))
+    ins_ = ', '.join(f'[{n}] "s"({n})' for n in SRDS) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in SIN + ([f'dbg{k}' for k in range(6)] if STAMPS else []))
     clob = ', '.join(f'"v{i}"' for i in range(N_HAND)) + ',\n      ' + ', '.join(f'"a{i}"' for i in range(256)) + ', "vcc", "scc", "memory"'
     return ('// GENERATED by gen_attn_bwd_sp.py -- do not edit; see that file for the register map and the schedule\n'
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')

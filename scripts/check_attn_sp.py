@@ -64,6 +64,39 @@ def torch_ref(x, H):
     return back(qproj.grad), back(K.grad), back(V.grad)
 
 
+def stamps(nwg, Nq):
+    """diagnostic build (-DSPX_STAMPS): shader cycles and 100 MHz ticks each workgroup spent in the asm statement"""
+    import ctypes
+    lib = hip.load()
+    if not hasattr(lib, 'crl_debug_spx_stamps'):
+        return
+    n = min(nwg, 4096)
+    buf = (ctypes.c_ulonglong * (2 * n))()
+    lib.crl_debug_spx_stamps(buf, 2 * n)
+    cyc = sorted(buf[2 * i] for i in range(n))
+    tick = sorted(buf[2 * i + 1] for i in range(n))
+    T = (Nq + 63) // 64 + 1
+    med_c, med_t = cyc[n // 2], tick[n // 2]
+    print(f'  stamps over {n} workgroups: median {med_c} cycles = {med_c / T:.0f} per tile pass = {med_c / T / 80:.1f} per MFMA; '
+          f'{med_t / 100:.1f} us -> in-kernel clock {med_c / med_t * 0.1:.3f} GHz (min {cyc[0]}, max {cyc[-1]} cycles)', flush=True)
+    if hasattr(lib, 'crl_debug_spx_trace') and T < 128:
+        import statistics
+        tr = (ctypes.c_ulonglong * (6 * 65 * 128))()
+        lib.crl_debug_spx_trace(tr)
+        seg = {k: [] for k in ('top wait', 'barrier', 'slot 0', 'slot 1', 'slot 2', 'slot 3')}
+        for wg in range(64):
+            st = lambda k, p: tr[(k * 65 + wg) * 128 + p]
+            for p in range(3, T - 1):           # pass p's stamps sit in row p + 1 (written at the top of the next pass)
+                s0, s1, s2, s3, s4, s5 = (st(k, p + 1) for k in range(6))
+                prev_end = st(5, p)
+                if min(s0, s1, s2, s3, s4, s5, prev_end) == 0:
+                    continue
+                seg['top wait'].append(s0 - prev_end); seg['barrier'].append(s1 - s0); seg['slot 0'].append(s2 - s1)
+                seg['slot 1'].append(s3 - s2); seg['slot 2'].append(s4 - s3); seg['slot 3'].append(s5 - s4)
+        print('  per-pass trace (cycles, median / p90 over 64 workgroups x passes): ' +
+              ', '.join(f'{k} {statistics.median(v):.0f} / {sorted(v)[int(len(v) * 0.9)]:.0f}' for k, v in seg.items() if v), flush=True)
+
+
 def main():
     modes = [1, 2]
     if '--modes' in sys.argv:
@@ -111,6 +144,7 @@ def main():
             ms = e0.elapsed_time(e1) / 20
             print(f'{name:12s} mode {mode}: {ms:.3f} ms per backward  ({8.0 * 64 * Nq * Nk * B * H / ms / 1e9:.0f} TFLOP/s algorithmic)', flush=True)
         hip.call('crl_attn_bwd_set_mode', 0)
+        stamps(B * H * ((Nk + 255) // 256), Nq)
     sys.exit(1 if bad else 0)
 
 
