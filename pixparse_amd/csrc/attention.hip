@@ -992,11 +992,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const int sw = swz64(ki);
   uint32_t adsw0 = dsw + ((0 ^ sw) << 4), adsw1 = dsw + ((1 ^ sw) << 4), adsw2 = dsw + ((2 ^ sw) << 4), adsw3 = dsw + ((3 ^ sw) << 4),
            adsw4 = dsw + ((4 ^ sw) << 4), adsw5 = dsw + ((5 ^ sw) << 4), adsw6 = dsw + ((6 ^ sw) << 4), adsw7 = dsw + ((7 ^ sw) << 4);
-  uint32_t atrs0 = sbase + SPX_DS + 32768 + (qh ? la.tr[1][0] : la.tr[0][0]), atrs1 = sbase + SPX_DS + 32768 + (qh ? la.tr[1][1] : la.tr[0][1]);
+  uint32_t atrs0 = sbase + SPX_DS + (qh ? la.tr[1][0] : la.tr[0][0]), atrs1 = sbase + SPX_DS + (qh ? la.tr[1][1] : la.tr[0][1]);
   uint32_t atrk0 = sbase + SPX_DS + (dbq ? la.tr[1][0] : la.tr[0][0]), atrk1 = sbase + SPX_DS + (dbq ? la.tr[1][1] : la.tr[0][1]);
   const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
   uint32_t sqv = sq.v, sdov = sdo.v, rcv = (uint32_t)lane * 4u;
-  uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2);
+  uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 8 * hh) * 2);   // 16 bytes per lane (the stream swaps lane halves)
   uint32_t dkv = (uint32_t)(((int64_t)(key0 + ki) * a.dk_rs + 4 * hh) * 2), dvv = (uint32_t)(((int64_t)(key0 + ki) * a.dv_rs + 4 * hh) * 2);
   const int kr0 = min(key0 + ki, a.Nk - 1), kr1 = min(key0 + 32 + ki, a.Nk - 1);
   uint32_t koff0 = (uint32_t)(((int64_t)kr0 * a.k_rs + 8 * hh) * 2), koff1 = (uint32_t)(((int64_t)kr1 * a.k_rs + 8 * hh) * 2);
@@ -1008,12 +1008,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
   const float s_dkscale = a.scale;
   const uint32_t s_iters = (uint32_t)nqt64 + 1u;   // the last pass only finishes dQ of the last tile (its other products see zero rows)
-  const uint32_t s_S = SPX_SLOT, s_m2S = (uint32_t)(-2 * SPX_SLOT);
   // running state: the DMA of pass t fetches tile t + 2; the slab offset advances before the stores of a pass (tile t - 1)
   uint32_t s_qoff = 2u * s_qstep, s_dooff = 2u * s_dostep, s_rcoff = 2u * 256u, s_slaboff = (uint32_t)(-2 * (int)s_slabstep);
-  uint32_t s_m0q = sbase + 2 * SPX_SLOT + wave * 1024, s_m0rc = sbase + 2 * SPX_SLOT + 16384 + wave * 256;
-  uint32_t s_cD = 2, s_cA = 1, s_cB = 1, s_dA = SPX_SLOT, s_dB = SPX_SLOT;
-  uint32_t s_tmp0, s_tmp1, s_cnt;
+  const uint32_t s_m0q = sbase + wave * 1024, s_m0rc = sbase + 16384 + wave * 256;     // + ring slot + piece: immediates of the unrolled passes
+  uint32_t s_tmp1, s_cnt;
 
   // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: whatever dS the clamped fragments of such keys produce, it meets a
   // zero K^T row in dQ), query tiles 0 and 1 -> ring slots 0 and 1

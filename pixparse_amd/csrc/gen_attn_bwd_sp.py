@@ -157,7 +157,7 @@ def dq_quarter(w):
     return out
 
 
-def valu_block(qb, kb):
+def valu_block(qb, kb, par=0):
     """exp / mul / cvt of block (qb, kb) and the four dS stores; returns dict name -> list of instructions in dependency order"""
     S, D, P, DS = V_S[kb], V_D[kb], V_P[kb], V_DS[kb]
     ex = [v_exp(S + r) for r in range(16)]
@@ -167,30 +167,30 @@ def valu_block(qb, kb):
     wr = []
     for ss in range(2):
         c0 = 4 * qb + 2 * ss
-        wr.append(ds_write_b64(f'adsw{c0}', DS + 4 * ss, 4096 * kb))
-        wr.append(ds_write_b64(f'adsw{c0 + 1}', DS + 4 * ss + 2, 4096 * kb))
+        wr.append(ds_write_b64(f'adsw{c0}', DS + 4 * ss, 4096 * kb + 32768 * par))
+        wr.append(ds_write_b64(f'adsw{c0 + 1}', DS + 4 * ss + 2, 4096 * kb + 32768 * par))
     return dict(exp=ex, mul=mu, cvtp=cp, cvtd=cd, wr=wr)
 
 
-def load_seeds(qb):
+def load_seeds(qb, ring=0):
     out = []
     for g in range(4):
-        out.append(ds_read_b128(V_SEEDL + 4 * g, 'aseed', 128 * qb + 32 * g))
-        out.append(ds_read_b128(V_SEEDD + 4 * g, 'aseed', 256 + 128 * qb + 32 * g))
+        out.append(ds_read_b128(V_SEEDL + 4 * g, 'aseed', ring * SLOT + 128 * qb + 32 * g))
+        out.append(ds_read_b128(V_SEEDD + 4 * g, 'aseed', ring * SLOT + 256 + 128 * qb + 32 * g))
     return out
 
 
-def load_qf(qb):
+def load_qf(qb, ring=0):
     out = []
     for ks in range(4):
-        out.append(ds_read_b128(V_QF + 4 * ks, f'arow{ks}', 4096 * qb))
-        out.append(ds_read_b128(V_DOF + 4 * ks, f'arow{ks}', 8192 + 4096 * qb))
+        out.append(ds_read_b128(V_QF + 4 * ks, f'arow{ks}', ring * SLOT + 4096 * qb))
+        out.append(ds_read_b128(V_DOF + 4 * ks, f'arow{ks}', ring * SLOT + 8192 + 4096 * qb))
     return out
 
 
-def load_tf(qb, ss):
+def load_tf(qb, ss, ring=0):
     out = []
-    off = (32 * qb + 16 * ss) * 128
+    off = ring * SLOT + (32 * qb + 16 * ss) * 128
     for f in range(4):
         db, tile = f & 1, (8192 if f < 2 else 0)
         out.append(ds_read_tr('v', tf(ss, f), f'atr{2 * db}', tile + off))
@@ -198,40 +198,47 @@ def load_tf(qb, ss):
     return out
 
 
-def load_dsf(w):
+def load_dsf(w, par=0):
     out = []
     for kk in range(4):
-        out.append(ds_read_tr('v', V_DSF + 4 * kk, 'atrs0', w * 8192 + kk * 2048))
-        out.append(ds_read_tr('v', V_DSF + 4 * kk + 2, 'atrs1', w * 8192 + kk * 2048))
+        out.append(ds_read_tr('v', V_DSF + 4 * kk, 'atrs0', 32768 * par + w * 8192 + kk * 2048))
+        out.append(ds_read_tr('v', V_DSF + 4 * kk + 2, 'atrs1', 32768 * par + w * 8192 + kk * 2048))
     return out
 
 
 def dq_store():
-    """dQ^T block -> bf16 in place -> four 8-byte stores into the slab (rows past Nq, and the whole tile -1, fall off the descriptor)"""
+    """dQ^T block -> bf16 in place -> slab (rows past Nq, and the whole tile -1, fall off the descriptor).  Pairs of 4-channel groups
+    are exchanged between the lane halves (v_permlane32_swap, guide T21) so that every lane owns 16 contiguous bytes: two 16-byte
+    stores per lane instead of four 8-byte ones (a store instruction costs the wave ~70 cycles here, whatever its width)."""
     cv, st = [], []
-    for g in range(4):
+    for g in (0, 2):
         b = V_DQ + 4 * g
         cv.append(v_cvt(b, b, b + 1))
         cv.append(v_cvt(b + 1, b + 2, b + 3))
-        st.append(I(f'buffer_store_dwordx2 {vr(b, 2)}, {op("slabv")}, {op("rslab")}, {op("s_slaboff")} offen offset:{16 * g}', 'vmem',
-                    reads=regs('v', b, 2) + ['slabv']))
+        cv.append(v_cvt(b + 2, b + 4, b + 5))
+        cv.append(v_cvt(b + 3, b + 6, b + 7))
+    for g in (0, 2):
+        b = V_DQ + 4 * g
+        cv.append(valu(f'v_permlane32_swap_b32 v{b}, v{b + 2}', [f'v{b}', f'v{b + 2}'], [f'v{b}', f'v{b + 2}'], kind='perm'))
+        cv.append(valu(f'v_permlane32_swap_b32 v{b + 1}, v{b + 3}', [f'v{b + 1}', f'v{b + 3}'], [f'v{b + 1}', f'v{b + 3}'], kind='perm'))
+        st.append(I(f'buffer_store_dwordx4 {vr(b, 4)}, {op("slabv")}, {op("rslab")}, {op("s_slaboff")} offen offset:{16 * g}\n\ts_nop 1', 'vmem',
+                    reads=regs('v', b, 4) + ['slabv']))
     return cv, st
 
 
-def dma_tile():
-    """the five LDS-DMA pieces of one wave for tile t + 2: two of Q, two of dO, one row-constant vector"""
+def dma_tile(ring):
+    """the five LDS-DMA pieces of one wave for tile t + 2 into ring slot `ring`: two of Q, two of dO, one row-constant vector"""
     out = []
-    def piece(m0expr_setup, srd, voff, soff, width):
-        ins = list(m0expr_setup)
+    def piece(setup, srd, voff, soff, width):
+        ins = list(setup)
         ins.append(I(f's_nop 0\n\tbuffer_load_{width} {op(voff)}, {op(srd)}, {soff} offen lds', 'vmem', reads=[voff], cost=12))
         return ins
-    out += piece([salu(f's_mov_b32 m0, {op("s_m0q")}')], 'rq', 'sqv', op('s_qoff'), 'dwordx4')
-    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 4096'), salu(f's_add_u32 {op("s_tmp1")}, {op("s_qoff")}, {op("s_q32")}'),
-                  salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rq', 'sqv', op('s_tmp1'), 'dwordx4')
-    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 8192'), salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rdo', 'sdov', op('s_dooff'), 'dwordx4')
-    out += piece([salu(f's_add_u32 {op("s_tmp0")}, {op("s_m0q")}, 12288'), salu(f's_add_u32 {op("s_tmp1")}, {op("s_dooff")}, {op("s_do32")}'),
-                  salu(f's_mov_b32 m0, {op("s_tmp0")}')], 'rdo', 'sdov', op('s_tmp1'), 'dwordx4')
-    out += piece([salu(f's_mov_b32 m0, {op("s_m0rc")}')], 'rrc', 'rcv', op('s_rcoff'), 'dword')
+    base = ring * SLOT
+    out += piece([salu(f's_add_u32 m0, {op("s_m0q")}, {base}')], 'rq', 'sqv', op('s_qoff'), 'dwordx4')
+    out += piece([salu(f's_add_u32 {op("s_tmp1")}, {op("s_qoff")}, {op("s_q32")}'), salu(f's_add_u32 m0, {op("s_m0q")}, {base + 4096}')], 'rq', 'sqv', op('s_tmp1'), 'dwordx4')
+    out += piece([salu(f's_add_u32 m0, {op("s_m0q")}, {base + 8192}')], 'rdo', 'sdov', op('s_dooff'), 'dwordx4')
+    out += piece([salu(f's_add_u32 {op("s_tmp1")}, {op("s_dooff")}, {op("s_do32")}'), salu(f's_add_u32 m0, {op("s_m0q")}, {base + 12288}')], 'rdo', 'sdov', op('s_tmp1'), 'dwordx4')
+    out += piece([salu(f's_add_u32 m0, {op("s_m0rc")}, {base}')], 'rrc', 'rcv', op('s_rcoff'), 'dword')
     return out
 
 
@@ -256,10 +263,13 @@ class Gaps:
         return sum(i.cost for i in self.g[gap])
 
 
-def build_iteration():
-    """returns (backbone: 80 MFMAs, gaps: 80 lists of fillers).  gap i = the instructions issued right after MFMA i"""
+def build_iteration(p):
+    """pass p of the six-fold unrolled loop (tile t = p mod 6): returns (backbone: 80 MFMAs, gaps: 80 lists of fillers); gap i = the
+    instructions issued right after MFMA i.  Ring slot of tile t = p mod 3, dS buffer of tile t = p mod 2: every LDS address of the
+    pass is a per-lane base register + an immediate."""
     bb = []
     G = Gaps(80)
+    ring_t, ring_n, par_w, par_r = p % 3, (p + 1) % 3, p & 1, (p + 1) & 1
     for s in range(4):
         qb, kb = s >> 1, s & 1
         g0 = 20 * s
@@ -272,7 +282,7 @@ def build_iteration():
         else:
             bb += m1 + m2 + dq
         # ---- VALU of block (qb, kb): exp r in gap r, mul one gap later, conversions trailing
-        vb = valu_block(qb, kb)
+        vb = valu_block(qb, kb, par_w)
         for r in range(16):
             G.put(g0 + r, vb['exp'][r])
             G.put(g0 + r + 1, vb['mul'][r])
@@ -283,57 +293,36 @@ def build_iteration():
         G.put(g0 + 19, vb['wr'][2]); G.put(g0 + 19, vb['wr'][3])
         # ---- dS^T fragments of this slot's dQ quarter
         if s == 3:
-            G.spread(g0 + 0, g0 + 6, load_dsf(s))     # used from MFMA 8 of the slot
+            G.spread(g0 + 0, g0 + 6, load_dsf(s, par_r))     # used from MFMA 8 of the slot
         else:
-            G.spread(g0 + 4, g0 + 11, load_dsf(s))    # used from MFMA 16
+            G.spread(g0 + 4, g0 + 11, load_dsf(s, par_r))    # used from MFMA 16
         if kb == 0:
             # row constants and row fragments of the NEXT 32-query block (this slot's M1 was the last user of the current ones)
             nqb = 1 - qb
-            G.spread(g0 + 2, g0 + 9, load_seeds(nqb))
-            G.spread(g0 + 8, g0 + 15, load_qf(nqb))
+            nring = ring_t if qb == 0 else ring_n     # slot 0 loads (t, qb 1), slot 2 loads (t + 1, qb 0)
+            G.spread(g0 + 2, g0 + 9, load_seeds(nqb, nring))
+            G.spread(g0 + 8, g0 + 15, load_qf(nqb, nring))
             # transposed fragments of THIS query block, first half (ss = 0: free once MFMA 11 of the slot has issued)
-            G.spread(g0 + 12, g0 + 19, load_tf(qb, 0))
+            G.spread(g0 + 12, g0 + 19, load_tf(qb, 0, ring_t))
         else:
-            G.spread(g0 + 0, g0 + 6, load_tf(qb, 1))  # ss = 1 (free since MFMA 15 of the previous slot); used from MFMA 12 / 16 of this slot
-    # ---- slot 1: LDS-DMA of tile t + 2 and the ring advance of the row-fragment / row-constant addresses (tile t -> t + 1)
+            G.spread(g0 + 0, g0 + 6, load_tf(qb, 1, ring_t))  # ss = 1 (free since MFMA 15 of the previous slot); used from MFMA 12 / 16 of this slot
+    # ---- slot 1: LDS-DMA of tile t + 2
     g0 = 20
-    dma = dma_tile()
-    G.spread(g0 + 7, g0 + 16, dma)
-    for k, name in enumerate(['arow0', 'arow1', 'arow2', 'arow3', 'aseed']):
-        G.put(g0 + 14 + k, valu(f'v_add_u32 {op(name)}, {op("s_dA")}, {op(name)}', [name], [name]))
+    G.spread(g0 + 7, g0 + 16, dma_tile((p + 2) % 3))
     # ---- slot 3: dQ conversion + stores (dQ MFMAs are 8..11 of the slot), address toggles, ring advance of the transposed addresses
     g0 = 60
     cv, st = dq_store()
-    G.spread(g0 + 14, g0 + 17, cv)
-    for k in range(4):
-        G.put(g0 + 18 + (k >> 1), st[k])
-    for k in range(4):
-        G.put(g0 + 8 + k, valu(f'v_add_u32 {op(f"atr{k}")}, {op("s_dB")}, {op(f"atr{k}")}', [f'atr{k}'], [f'atr{k}']))
+    G.spread(g0 + 14, g0 + 18, cv)
     for k in range(2):
-        G.put(g0 + 12 + k, valu(f'v_xor_b32 {op(f"atrs{k}")}, 0x8000, {op(f"atrs{k}")}', [f'atrs{k}'], [f'atrs{k}']))
+        G.put(g0 + 19, st[k])
     return bb, G
 
 
 def scalar_tail():
-    """per-iteration scalar bookkeeping, placed in the last gaps of the iteration (after the last LDS write / store that uses them)"""
-    S = SLOT
-    t = []
-    # running DMA source offsets and slab offset
-    t.append(salu(f's_add_u32 {op("s_qoff")}, {op("s_qoff")}, {op("s_qstep")}'))
-    t.append(salu(f's_add_u32 {op("s_dooff")}, {op("s_dooff")}, {op("s_dostep")}'))
-    t.append(salu(f's_add_u32 {op("s_rcoff")}, {op("s_rcoff")}, 256'))
-    # ring positions: DMA destination slot (tile t + 2), row-fragment addresses (tile t + 1 -> t + 2), transposed addresses (t -> t + 1)
-    # each is a counter 0..2; the address delta is +S, or -2S when the counter wraps
-    for cnt, m0s, delta in (('s_cD', ('s_m0q', 's_m0rc'), None), ('s_cA', (), 's_dA'), ('s_cB', (), 's_dB')):
-        t.append(salu(f's_add_u32 {op(cnt)}, {op(cnt)}, 1'))
-        t.append(salu(f's_cmp_eq_u32 {op(cnt)}, 3'))
-        t.append(salu(f's_cselect_b32 {op(cnt)}, 0, {op(cnt)}'))
-        t.append(salu(f's_cselect_b32 {op("s_tmp0")}, {op("s_m2S")}, {op("s_S")}'))
-        if delta:
-            t.append(salu(f's_mov_b32 {op(delta)}, {op("s_tmp0")}'))
-        for m in m0s:
-            t.append(salu(f's_add_u32 {op(m)}, {op(m)}, {op("s_tmp0")}'))
-    return t
+    """per-pass scalar bookkeeping: the running DMA source offsets (tile t + 2 -> t + 3)"""
+    return [salu(f's_add_u32 {op("s_qoff")}, {op("s_qoff")}, {op("s_qstep")}'),
+            salu(f's_add_u32 {op("s_dooff")}, {op("s_dooff")}, {op("s_dostep")}'),
+            salu(f's_add_u32 {op("s_rcoff")}, {op("s_rcoff")}, 256')]
 
 
 # timing-only experiments (WRONG RESULTS): SPX_DROP=class,class,... removes instruction classes from the loop body
@@ -393,12 +382,13 @@ class Hazards:
                 need = k
         if need is not None:
             outstanding_after = len(self.pending) - 1 - need
-            self.out.append(I(f's_waitcnt lgkmcnt({min(outstanding_after, 15)})', 'wait'))
+            if not (in_loop[0] and 'wait' in DROP):
+                self.out.append(I(f's_waitcnt lgkmcnt({min(outstanding_after, 15)})', 'wait'))
             self.pending = self.pending[need + 1:] if outstanding_after <= 15 else []
             self.recent_valu = []          # a wait is an instruction between the VALU and the consumer
             self.last_trans = None
         # ---- VALU result -> MFMA operand: two wait states
-        if ins.kind == 'mfma':
+        if ins.kind in ('mfma', 'perm'):
             hazard = 0
             for age, wr in self.recent_valu:
                 if wr & set(ins.reads):
@@ -407,7 +397,7 @@ class Hazards:
                 self.out.append(I(f's_nop {hazard - 1}', 'nop'))
                 self.recent_valu = [(a + hazard, w) for a, w in self.recent_valu]
         # ---- MFMA result -> VALU / LDS / store reading it: needs the MFMA (8 passes) finished; two later MFMAs guarantee that
-        if ins.kind in ('valu', 'trans', 'ds', 'vmem'):
+        if ins.kind in ('valu', 'trans', 'ds', 'vmem', 'perm'):
             for r in ins.reads:
                 if r in self.mfma_written and self.n_mfma - self.mfma_written[r] < 3:
                     raise RuntimeError(f'MFMA result {r} read too early by: {ins.text}')
@@ -420,7 +410,7 @@ class Hazards:
         self.out.append(ins)
         # ---- bookkeeping
         self.recent_valu = [(a + 1, w) for a, w in self.recent_valu if a + 1 < 3]
-        if ins.kind in ('valu', 'trans'):
+        if ins.kind in ('valu', 'trans', 'perm'):
             self.recent_valu.append((0, set(ins.writes)))
         self.last_trans = set(ins.writes) if ins.kind == 'trans' else None
         if ins.kind == 'ds':
@@ -448,9 +438,9 @@ class Hazards:
 VOPS = ['arow0', 'arow1', 'arow2', 'arow3', 'atr0', 'atr1', 'atr2', 'atr3', 'aseed'] + [f'adsw{i}' for i in range(8)] + \
        ['atrs0', 'atrs1', 'sqv', 'sdov', 'rcv', 'slabv', 'dkv', 'dvv', 'atrk0', 'atrk1', 'koff0', 'koff1', 'voff0', 'voff1']
 SRDS = ['rq', 'rdo', 'rrc', 'rk', 'rv', 'rdk', 'rdv', 'rslab']
-SIN = ['s_qstep', 's_dostep', 's_q32', 's_do32', 's_slabstep', 's_dk32', 's_dv32', 's_dkscale', 's_iters', 's_S', 's_m2S']
-SRW = ['s_qoff', 's_dooff', 's_rcoff', 's_slaboff', 's_m0q', 's_m0rc', 's_cD', 's_cA', 's_cB', 's_dA', 's_dB']
-STMP = ['s_tmp0', 's_tmp1', 's_cnt']
+SIN = ['s_qstep', 's_dostep', 's_q32', 's_do32', 's_slabstep', 's_dk32', 's_dv32', 's_dkscale', 's_iters', 's_m0q', 's_m0rc']
+SRW = ['s_qoff', 's_dooff', 's_rcoff', 's_slaboff']
+STMP = ['s_tmp1', 's_cnt']
 
 
 def generate():
@@ -486,44 +476,43 @@ def generate():
     E(I('s_nop 7\n\ts_nop 7', 'nop'))
     H.settle_mfma()
     E(salu(f's_mov_b32 {op("s_cnt")}, {op("s_iters")}'))
-    # ================================================================= loop
-    bb, G = build_iteration()
-    tail = scalar_tail()
-    # scalar tail + dS write-address toggle in the last gaps
-    for k, ins in enumerate(tail):
-        G.put(72 + (k * 7) // len(tail), ins)
-    # the slab offset advances BEFORE this iteration's stores (they come in the last gaps): it starts two tiles back
-    G.put(1, salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
+    # ================================================================= loop, unrolled over six passes (ring of 3 x dS double buffer)
     if STAMPS:
         H.out.append(I('\n\t'.join(f's_mov_b64 %[st{k}], 0' for k in range(6)), 'salu'))
     H.out.append(I('LOOP%=:', 'label'))
     in_loop[0] = True
-    # top of the iteration: tile t + 1 landed (the four slab stores of the previous iteration may still be in flight), this wave's dS
-    # stores and every LDS read of the previous iteration are complete
-    H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
-    if STAMPS:
-        # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
-        H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
-                       '\n\ts_add_u32 %[s_dbgoff], %[s_dbgoff], 8\n\ts_memtime %[st0]', 'salu'))
-    E(I('s_barrier', 'barrier'))
-    if STAMPS:
-        H.out.append(I('s_memtime %[st1]', 'salu'))
-    # the loop body starts from a settled matrix pipe only on the first pass; the distances are checked as if it were not
-    for i, m in enumerate(bb):
-        E(m)
-        for ins in G.g[i]:
-            E(ins)
-        if STAMPS and i in STAMP_AT:
-            H.out.append(I(f's_memtime %[st{STAMP_AT[i]}]', 'salu'))
-    # dS write addresses: toggle the buffer (every write of this tile has been issued)
-    for c0 in range(8):
-        E(valu(f'v_xor_b32 {op(f"adsw{c0}")}, 0x8000, {op(f"adsw{c0}")}', [f'adsw{c0}'], [f'adsw{c0}']))
-    if STAMPS:
-        H.out.append(I('s_memtime %[st5]', 'salu'))
-    E(salu(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1'))
-    E(salu(f's_cmp_lg_u32 {op("s_cnt")}, 0'))
-    E(I('s_cbranch_scc1 LOOP%=', 'branch'))
+    Gs = []
+    for p in range(6):
+        bb, G = build_iteration(p)
+        Gs.append(G)
+        for k, ins in enumerate(scalar_tail()):
+            G.put(72 + 2 * k, ins)
+        # the slab offset advances BEFORE this pass's stores (they come in the last gaps): it starts two tiles back
+        G.put(1, salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
+        # top of the pass: tile t + 1 landed (the two slab stores of the previous pass may still be in flight), this wave's dS
+        # stores and every LDS read of the previous pass are complete
+        H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
+        if STAMPS:
+            # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
+            H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
+                           '\n\ts_add_u32 %[s_dbgoff], %[s_dbgoff], 8\n\ts_memtime %[st0]', 'salu'))
+        E(I('s_barrier', 'barrier'))
+        if STAMPS:
+            H.out.append(I('s_memtime %[st1]', 'salu'))
+        for i, m in enumerate(bb):
+            E(m)
+            for ins in G.g[i]:
+                E(ins)
+            if STAMPS and i in STAMP_AT:
+                H.out.append(I(f's_memtime %[st{STAMP_AT[i]}]', 'salu'))
+        if STAMPS:
+            H.out.append(I('s_memtime %[st5]', 'salu'))
+        E(salu(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1'))
+        E(salu(f's_cmp_eq_u32 {op("s_cnt")}, 0'))
+        E(I('s_cbranch_scc1 DONE%=' if p < 5 else 's_cbranch_scc0 LOOP%=', 'branch'))
     in_loop[0] = False
+    H.out.append(I('DONE%=:', 'label'))
+    G = Gs[0]
     # ================================================================= epilogue: dK (scaled), dV -> bf16 -> bounds-checked stores
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
     if STAMPS:
