@@ -86,7 +86,7 @@ def time_kernel(fn, iters=3):
 
 
 KERNEL_NAMES = ['attn_fwd_pre_kernel<false>', 'attn_fwd_pre_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
-                'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>', 'attn_bwd_fused_kernel<0>', 'attn_dq_reduce_kernel']
+                'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>', 'attn_bwd_spx_kernel', 'attn_dq_reduce_kernel']
 
 
 def collect_live_profile(steps):
@@ -112,7 +112,7 @@ def collect_live_profile(steps):
     achieved = work[i] / (ms[i] * 1e-3) / 1e12
     # the WHOLE attention backward (every backward launch of the step, both passes or the fused pass): algorithmic FLOPs = 2 x forward
     # (dV, dP, dK, dQ; recomputed products not credited) over the summed duration
-    bwd = [j for j, nm in enumerate(KERNEL_NAMES) if 'bwd' in nm and launches[j]]
+    bwd = [j for j, nm in enumerate(KERNEL_NAMES) if ('bwd' in nm or 'dq_reduce' in nm) and launches[j]]     # the slab reduce of the single-pass form is part of the backward
     bwd_ms, bwd_work = sum(ms[j] for j in bwd), sum(work[j] for j in bwd)
     fwd = [j for j, nm in enumerate(KERNEL_NAMES) if 'fwd' in nm and launches[j]]
     att = {'attention_bwd_total': {'ms_per_step': round(bwd_ms / steps, 2), 'tflops': round(bwd_work / (bwd_ms * 1e-3) / 1e12, 1),
@@ -387,7 +387,7 @@ def main():
             # (shape key of scripts/pmc_traffic.py: grid = query tiles x B x H workgroups of 256 threads -- for the dK/dV pass the grid of
             # the dQ pass launched right before it) next to that shape's algorithmic bytes (each operand once)
             grid, algo = None, None
-            if m.enc_kind == 'vit' and live_prof['kernel'].endswith('<false>'):
+            if m.enc_kind == 'vit' and live_prof['kernel'] in ('attn_fwd_pre_kernel<false>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dq_kernel<false>'):
                 enc_ = m._engines[0]
                 tiles = (enc_.N + 127) // 128
                 grid = tiles * args.batch * enc_.heads * 256

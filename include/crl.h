@@ -153,12 +153,15 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
  * dq/dk/dv strides as q/k/v.  Two forms (same results up to bf16 rounding of dq; both deterministic, no float atomics):
  *   two-pass    dQ pass (recomputes S, dP; produces the row constants) then dK/dV pass (recomputes S, dP): 7 MFMA products per tile;
  *   single pass (non-causal, ws >= crl_attn_bwd_ws_bytes(...) > 0): one recomputation feeds dK, dV and dQ -- 5 products; a
- *               workgroup owns 512 keys of a head, so dQ is a sum over the key blocks: every 256-key half writes its partial as a
- *               bf16 [B, Nq, H*64] slab into ws and a reduce pass adds the ceil(Nk / 256) slabs in fixed order in fp32, applies
- *               `scale` and rounds to dq.
+ *               workgroup = 4 waves owns 256 keys of a head (one wave per SIMD with the whole register file: dK^T / dV^T accumulators,
+ *               K / V row fragments and the K^T fragments of its dQ block stay in registers; only dS crosses LDS), so dQ is a sum over
+ *               the key blocks: every block writes its partial as a bf16 [B, Nq, H*64] slab into ws and a reduce pass adds the
+ *               ceil(Nk / 256) slabs in fixed order in fp32, applies `scale` and rounds to dq.  With q_prescaled the kernel is one
+ *               hand-placed instruction stream (csrc/gen_attn_bwd_sp.py); without, the C++ form of the same algorithm (slow: tests).
  * crl_attn_bwd_ws_bytes: 0 when the two-pass form will run.
- * crl_attn_bwd_set_mode: 0 = auto = two-pass (measured faster on gfx950: the single pass is bound by LDS traffic, csrc/attention.hip),
- *   1 = two-pass, 2 = single pass whenever legal (non-causal). */
+ * crl_attn_bwd_set_mode: 0 = auto: single pass for non-causal problems with Nq >= 2048, Nk >= 1024 and a prescaled q (the ViT encoders:
+ *   same-box 3.29 against 3.65 ms per layer at B 8, H 16, N 6189), two-pass otherwise; 1 = two-pass; 2 = single pass whenever legal
+ *   (non-causal); 3 = single pass in its C++ form (reference of the hand-placed stream: bit-identical results). */
 size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
 int crl_attn_bwd_set_mode(int mode);
 int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
@@ -181,7 +184,7 @@ int crl_attn_dropout_mask(void* keep_u8, int B, int H, int Nq, int Nk, float p, 
 #define CRL_K_ATTN_FWD 0        /* attn_fwd_kernel<false>,      + 1 = <true> (causal) */
 #define CRL_K_ATTN_BWD_DKDV 2   /* attn_bwd_dkdv_kernel<false>, + 1 = <true> */
 #define CRL_K_ATTN_BWD_DQ 4     /* attn_bwd_dq_kernel<false>,   + 1 = <true> */
-#define CRL_K_ATTN_BWD_FUSED 6  /* attn_bwd_fused_kernel (single-pass backward; work = the whole algorithmic backward) */
+#define CRL_K_ATTN_BWD_FUSED 6  /* attn_bwd_spx_kernel / attn_bwd_sp_kernel (single-pass backward; work = the whole algorithmic backward) */
 #define CRL_K_ATTN_DQ_REDUCE 7  /* attn_dq_reduce_kernel (sum of the partial-dQ slabs; no FLOPs credited) */
 #define CRL_K_COUNT 8
 /* Measurement aid (never on the product path): n_cus workgroups that each take a whole CU (all 160 KiB of its LDS) and sleep

@@ -1139,14 +1139,17 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
 }
 
 static int g_bwd_parts = 7;
-static int g_bwd_mode = 0;      // 0 auto (= two-pass: the faster form on gfx950, see the fused kernel's header), 1 two-pass, 2 fused single pass whenever legal
+static int g_bwd_mode = 0;      // 0 auto (single pass for long non-causal sequences with a prescaled q), 1 two-pass, 2 single pass whenever legal, 3 its C++ form
 extern "C" int crl_attn_bwd_set_mode(int mode) {
   if (mode < 0 || mode > 3) { crl_set_error("crl_attn_bwd_set_mode: 0 auto, 1 two-pass, 2 single pass, 3 single pass (C++ reference form)"); return -1; }
   g_bwd_mode = mode;
   return 0;
 }
+// auto: the single pass pays from a few dozen query tiles per workgroup on (its prologue / epilogue -- K^T fragments, 128 accumulators in
+// and out -- cost as much as ~6 tile passes): the ViT encoders (N = 2401 ... 24 935), not the decoder's cross-attention (Nq = 1023)
 static bool bwd_fused_wanted(int Nq, int Nk, int causal) {
-  return !causal && g_bwd_mode >= 2 && g_bwd_parts == 7;
+  if (causal || g_bwd_parts != 7) return false;
+  return g_bwd_mode >= 2 || (g_bwd_mode == 0 && Nq >= 2048 && Nk >= 1024);
 }
 // bf16 partial-dQ slabs of the fused backward: ceil(Nk / 256) x [B, Nq, H * 64]; 0 = the two-pass form runs (no workspace needed)
 extern "C" size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal) {
@@ -1205,7 +1208,8 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
   }
-  const size_t need = drop ? 0 : crl_attn_bwd_ws_bytes(B, H, Nq, Nk, causal);     // the single-pass form has no dropout variant
+  // the single-pass form has no dropout variant; in auto mode it is the hand-placed stream or nothing (that one wants a prescaled q)
+  const size_t need = (drop || (g_bwd_mode == 0 && !q_prescaled)) ? 0 : crl_attn_bwd_ws_bytes(B, H, Nq, Nk, causal);
   if (need && ws && ws_bytes >= need) {
     // ---- fused single pass: row constants, then dK / dV / partial dQ slabs from one recomputation, then the slab reduce
     CRL_CHECK(((uintptr_t)ws % 16) == 0 && (dq_rs % 8) == 0, "%s: workspace / dq must be 16-byte aligned", who);

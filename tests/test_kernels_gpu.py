@@ -108,29 +108,42 @@ def test_gemm_column_scale(dev):
 
 
 # ------------------------------------------------------------------------------------------- attention backward, single-pass form
-@pytest.mark.parametrize('B,H,Nq,Nk', [(1, 2, 300, 700), (2, 1, 64, 512), (1, 2, 100, 45), (1, 2, 1023, 1300)])
-def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
+@pytest.mark.parametrize('B,H,Nq,Nk,pre', [(1, 2, 300, 700, True), (2, 1, 64, 512, True), (1, 2, 100, 45, True), (1, 2, 1023, 1300, True),
+                                           (2, 2, 577, 577, True), (1, 1, 2100, 1100, True), (1, 2, 300, 700, False), (1, 1, 130, 260, False)])
+def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk, pre):
     """crl_attn_bwd_set_mode(2): dK, dV and dQ from ONE recomputation of S / dP (5 MFMA products), dQ as a sum of per-key-block bf16 slabs
-    reduced in fixed order.  Against the default two-pass form: dV bit for bit, dK to 1e-4, dQ within the extra bf16 rounding of the partials;
-    against fp32 torch: the tolerance of the two-pass tests; two runs bit-identical.  Shapes cover a ragged last key block, fewer keys
-    than one workgroup owns (512), ragged query tiles and the cross-attention aspect ratio."""
+    reduced in fixed order.  pre: q prescaled = the hand-placed instruction stream (attn_bwd_spx_kernel), else the C++ form of the same
+    algorithm; mode 3 runs the C++ form on the prescaled problem too and must agree with the stream BIT FOR BIT.  Against the two-pass
+    form: dV bit for bit, dK to 1e-4, dQ within the extra bf16 rounding of the partials; against fp32 torch: the tolerance of the two-pass
+    tests; two runs bit-identical.  Shapes cover a ragged last key block, fewer keys than one workgroup owns (256), ragged query tiles,
+    more tiles than the ring / unroll period, strided q | k | v views and the cross-attention aspect ratio; the last prescaled shape is
+    long enough for mode 0 (auto) to pick the single pass by itself."""
     from pixparse_amd import hip, ops
     D, scale = H * 64, 0.125
+    c = scale * ops.LOG2E if pre else 1.0
     g = torch.Generator(device=dev).manual_seed(Nq + Nk)
-    q, do = (torch.randn(B, Nq, D, generator=g, device=dev).to(BF16) for _ in range(2))
-    k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(BF16) for _ in range(2))
-    o = torch.empty_like(q)
+    if Nq == Nk:       # column blocks of one projection output, like the ViT blocks
+        qkv = torch.randn(B, Nq, 3 * D, generator=g, device=dev)
+        qkv[:, :, :D] *= c
+        qkv = qkv.to(BF16)
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    else:
+        q = (torch.randn(B, Nq, D, generator=g, device=dev) * c).to(BF16)
+        k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(BF16) for _ in range(2))
+    do = torch.randn(B, Nq, D, generator=g, device=dev).to(BF16)
+    o = torch.empty(B, Nq, D, dtype=BF16, device=dev)
     lse = torch.empty(B, H, Nq, device=dev)
-    ops.attn_fwd(q, k, v, o, lse, H, scale, False)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False, q_prescaled=pre)
     delta = torch.empty(2, B, H, Nq, device=dev)
 
     def bwd(mode):
-        dq, dk, dv = torch.full_like(q, float('nan')), torch.full_like(k, float('nan')), torch.full_like(v, float('nan'))
+        dq, dk, dv = (torch.full((B, n, D), float('nan'), dtype=BF16, device=dev) for n in (Nq, Nk, Nk))
         hip.call('crl_attn_bwd_set_mode', mode)
         try:
-            assert (hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 0) > 0) == (mode == 2)
+            auto = Nq >= 2048 and Nk >= 1024
+            assert (hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 0) > 0) == (mode >= 2 or (mode == 0 and auto))
             assert hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 1) == 0          # causal: always two-pass
-            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False)
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False, q_prescaled=pre)
         finally:
             hip.call('crl_attn_bwd_set_mode', 0)
         return dq, dk, dv
@@ -141,13 +154,19 @@ def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk):
     # forms compute in different kernels (a last-bit difference in delta flips a bf16 rounding of dS here and there)
     assert torch.equal(dv1, dv2) and rel(dk1, dk2) < 1e-4
     assert rel(dq1, dq2) < 1e-2
-    hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2).requires_grad_(True)
-    Q, K, V = hd(q), hd(k), hd(v)
-    (torch.softmax(Q @ K.transpose(-1, -2) * scale, -1) @ V).backward(do.float().reshape(B, Nq, H, 64).transpose(1, 2))
+    if pre:
+        dq3, dk3, dv3 = bwd(3)
+        assert torch.equal(dq3, dq1) and torch.equal(dk3, dk1) and torch.equal(dv3, dv1)
+        dq0, dk0, dv0 = bwd(0)
+        ref0 = (dq1, dk1, dv1) if (Nq >= 2048 and Nk >= 1024) else (dq2, dk2, dv2)
+        assert torch.equal(dq0, ref0[0]) and torch.equal(dk0, ref0[1]) and torch.equal(dv0, ref0[2])
+    hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    Qp, K, V = (hd(q) / c).requires_grad_(True), hd(k).requires_grad_(True), hd(v).requires_grad_(True)
+    (torch.softmax(Qp @ K.transpose(-1, -2) * scale, -1) @ V).backward(hd(do))
     back = lambda t: t.transpose(1, 2).reshape(B, -1, D)
-    assert rel(dq1, back(Q.grad)) < 2e-2 and rel(dk1, back(K.grad)) < 2e-2 and rel(dv1, back(V.grad)) < 2e-2
-    dq3, dk3, dv3 = bwd(2)
-    assert torch.equal(dq3, dq1) and torch.equal(dk3, dk1) and torch.equal(dv3, dv1)
+    assert rel(dq1, back(Qp.grad)) < 2e-2 and rel(dk1, back(K.grad)) < 2e-2 and rel(dv1, back(V.grad)) < 2e-2
+    dq4, dk4, dv4 = bwd(2)
+    assert torch.equal(dq4, dq1) and torch.equal(dk4, dk1) and torch.equal(dv4, dv1)
 
 
 # ------------------------------------------------------------------------------------------- GEMM
