@@ -58,6 +58,12 @@ int crl_gemm_set_policy(int policy);
 /* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
    < 0 = never cut.  Process-wide. */
 int crl_gemm_set_quant_cost(float c);
+/* Wave-quantisation cost model: microseconds per round of 256x256 tiles = a + b K / 1024 (defaults fitted on one MI355X).
+ * crl_gemm_calibrate: one-off and SYNCHRONISING -- times one / two rounds at K = 1024 / 4096 on random bf16 operands placed in ws
+ * (>= crl_gemm_calibrate_ws_bytes(), ~340 MB) and refits a, b for THIS device; 0 = refitted, 1 = implausible measurement (defaults kept). */
+size_t crl_gemm_calibrate_ws_bytes(void);
+int crl_gemm_calibrate(void* ws, size_t ws_bytes, void* stream);
+int crl_gemm_model(float* round_a_us, float* round_b_us, int* calibrated);
 /* Data-parallel runs share the GPU with RCCL's all-reduce kernels (ref: DistributedDataParallel's bucket all-reduces,
  * task/task_cruller_pretrain.py:181-189, overlapping backward).  The 256-row kernels are persistent: one (two) resident
  * workgroup(s) per CU.

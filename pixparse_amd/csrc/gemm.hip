@@ -217,14 +217,24 @@ static int g_dynamic = 1;          // 1 = resident workgroups pull tiles from ti
 __device__ uint32_t g_sched_state[gemmc::CRL_SCHED_SLOTS * gemmc::CRL_SCHED_WORDS];   // zero at module load; every launch leaves its slot zeroed
 int crl_gemm_cus() { return CHIP_CUS - g_reserved_cus; }
 bool crl_gemm_dynamic() { return g_dynamic != 0; }
-uint32_t* crl_sched_slot() {
+// The pool is a ring: launch n + CRL_SCHED_SLOTS reuses the slot of launch n, which is safe only if the two are ordered -- i.e. issued
+// on ONE stream (the last workgroup of a launch zeroes its slot before the kernel ends).  The first stream that asks owns the pool;
+// a persistent GEMM launched on any OTHER stream gets *ok = true with no slot and walks its tiles statically (same results, no shared
+// state) instead of racing on the counters.
+uint32_t* crl_sched_slot(hipStream_t stream, bool* ok) {
   static uint32_t* base = nullptr;
   static std::atomic<unsigned> seq{0};
+  static std::atomic<void*> owner{nullptr};
+  static std::atomic<bool> owned{false};
+  *ok = true;
   if (!base) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_state)) != hipSuccess || !p) { crl_set_error("crl_gemm_bf16: no scheduler state"); return nullptr; }
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_state)) != hipSuccess || !p) { crl_set_error("crl_gemm_bf16: no scheduler state"); *ok = false; return nullptr; }
     base = (uint32_t*)p;
   }
+  bool expected = false;
+  if (owned.compare_exchange_strong(expected, true)) owner.store((void*)stream);
+  if (owner.load() != (void*)stream) return nullptr;
   return base + (size_t)(seq.fetch_add(1) % gemmc::CRL_SCHED_SLOTS) * gemmc::CRL_SCHED_WORDS;
 }
 extern "C" int crl_gemm_set_reserved_cus(int n) {
@@ -288,13 +298,18 @@ static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
 // 349, kv dgrad 204 -> 185); cutting MORE than the last partial round (the round-2 model priced a round of small tiles at 0.32 of a
 // big one; it is 0.75) never does.  Returns R, or -1 for "no cut".
 static float g_quant_cost = 1.0f;   // multiplies the modelled cost of the remainder launch; < 0: never cut (tuning aid)
+// microseconds per round of 256x256 tiles = a + b K / 1024.  The defaults were fitted on one box (round 3); crl_gemm_calibrate() replaces
+// them by what THIS device sustains (boxes of the pool differ by ~5 % in their GEMM rate).  The fixed costs of the
+// model (a second launch 14 us, a reduce launch 8 us, the 3 us hysteresis) are dispatch-side and stay.
+static float g_round_a = 5.0f, g_round_b = 22.0f;
+static int g_calibrated = 0;
 extern "C" int crl_gemm_set_quant_cost(float c) { g_quant_cost = c; return 0; }
 static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap);
 static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
   if (layout == CRL_TN || g_quant_cost < 0.f) return -1;
   const int64_t ntn = (N + 255) / 256, rmax = M / 256, ncu = crl_gemm_cus();
   const int64_t wmax = (((M + 255) / 256) * ntn + ncu - 1) / ncu;   // rounds of the uncut launch
-  auto round_us = [](double k) { return 5.0 + 22.0 * k / 1024.0; }; // one round of 256x256 tiles (plain epilogue, sustained clock)
+  auto round_us = [](double k) { return (double)g_round_a + (double)g_round_b * k / 1024.0; }; // one round of 256x256 tiles (plain epilogue, sustained clock)
   // uncut: the tiles of the last partial round start while the stragglers of the round before still run (dynamic schedule)
   double best_cost = ((double)wmax - 0.2) * round_us((double)K);
   int64_t best_r = -1;
@@ -340,6 +355,76 @@ static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64
   if (ns > 32) ns = 32;
   while (ns > 1 && nk / ns < 4) --ns;       // slabs of >= 4 K tiles
   return ns;
+}
+
+namespace {
+// bf16 values in (-1, 1) from a hash of the element index: calibration operands (constant data would run at a higher clock than real activations)
+__global__ void calib_fill_kernel(uint32_t* __restrict__ p, size_t n2) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2) return;
+  uint32_t x = (uint32_t)i * 0x9E3779B1u + 0x7F4A7C15u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  const float a = (float)(int)(x & 0xffff) * (1.0f / 32768.0f) - 1.0f, b = (float)(int)(x >> 16) * (1.0f / 32768.0f) - 1.0f;
+  p[i] = pack_bf2(a, b);
+}
+}  // namespace
+
+extern "C" int crl_gemm_model(float* round_a_us, float* round_b_us, int* calibrated) {
+  if (round_a_us) *round_a_us = g_round_a;
+  if (round_b_us) *round_b_us = g_round_b;
+  if (calibrated) *calibrated = g_calibrated;
+  return 0;
+}
+extern "C" size_t crl_gemm_calibrate_ws_bytes() { return ((size_t)32768 * 4096 + (size_t)1024 * 4096 + (size_t)32768 * 1024) * 2; }
+// One-off, SYNCHRONISING: times one and two rounds of 256x256 tiles (N = 1024: 256 / 512 tiles) at K = 1024 and K = 4096 on random bf16
+// operands in `ws` and refits round_us(K) = a + b K / 1024 of the wave-quantisation model.  Returns 0 (refitted), 1 (measurement
+// implausible: defaults kept), < 0 on error.
+extern "C" int crl_gemm_calibrate(void* ws, size_t ws_bytes, void* stream) {
+  CRL_CHECK(ws && ws_bytes >= crl_gemm_calibrate_ws_bytes() && ((uintptr_t)ws % 16) == 0, "crl_gemm_calibrate: needs %zu bytes of 16-byte aligned scratch", crl_gemm_calibrate_ws_bytes());
+  hipStream_t s = as_stream(stream);
+  u16* A = (u16*)ws;
+  u16* B = A + (size_t)32768 * 4096;
+  u16* C = B + (size_t)1024 * 4096;
+  const size_t n2 = ((size_t)32768 * 4096 + (size_t)1024 * 4096) / 2;
+  calib_fill_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>((uint32_t*)ws, n2);
+  CRL_LAUNCH_CHECK("crl_gemm_calibrate(fill)");
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { crl_set_error("crl_gemm_calibrate: cannot create events"); return -2; }
+  const float saved_cost = g_quant_cost;
+  const int saved_policy = g_policy;
+  g_quant_cost = -1.f;      // the timed launches are never cut
+  g_policy = 2;
+  double r[2] = {0, 0};
+  int rc = 0;
+  for (int ki = 0; ki < 2 && rc == 0; ++ki) {
+    const int64_t K = ki == 0 ? 1024 : 4096;
+    double t[2] = {0, 0};
+    for (int rounds = 1; rounds <= 2 && rc == 0; ++rounds) {
+      const int64_t M = 16384 * rounds;
+      auto run = [&]() { return crl_gemm_bf16(CRL_NT, CRL_EPI_BF16, M, 1024, K, A, 4096, B, 4096, nullptr, C, 1024, nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0, stream); };
+      for (int w = 0; w < 3 && rc == 0; ++w) rc = run();
+      hipEventRecord(e0, s);
+      for (int i = 0; i < 8 && rc == 0; ++i) rc = run();
+      hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) rc = -2;
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      t[rounds - 1] = (double)ms * 1000.0 / 8.0;
+    }
+    r[ki] = t[1] - t[0];
+  }
+  g_quant_cost = saved_cost;
+  g_policy = saved_policy;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc) return rc;
+  const double b = (r[1] - r[0]) / 3.0, a = r[0] - b;
+  // plausible: within a factor 2 of the fitted defaults and a non-negative fixed part
+  if (!(b > 11.0 && b < 44.0 && a > -5.0 && a < 30.0)) return 1;
+  g_round_a = (float)(a < 0.0 ? 0.0 : a);
+  g_round_b = (float)b;
+  g_calibrated = 1;
+  return 0;
 }
 
 extern "C" int crl_gemm_set_policy(int policy) {

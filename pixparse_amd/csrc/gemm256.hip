@@ -303,7 +303,7 @@ int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
   const int ncu = crl_gemm_cus();
   if (nsplit == 1 && grid_x > ncu) {   // one resident workgroup per CU pulls tiles from the launch's ticket counters
     grid_x = ncu;
-    if (crl_gemm_dynamic()) { b.sched = crl_sched_slot(); if (!b.sched) return -2; }
+    if (crl_gemm_dynamic()) { bool ok; b.sched = crl_sched_slot(s, &ok); if (!ok) return -2; }
   }
 #endif
 #ifdef G_GRID_CAP

@@ -240,7 +240,7 @@ int launch2x_one(const GemmArgs& a, hipStream_t s) {
   const int nres = 2 * crl_gemm_cus();         // two resident workgroups per CU
   if (G2X_PERSIST && grid > nres) {
     grid = nres;
-    if (crl_gemm_dynamic()) { b.sched = crl_sched_slot(); if (!b.sched) return -2; }
+    if (crl_gemm_dynamic()) { bool ok; b.sched = crl_sched_slot(s, &ok); if (!ok) return -2; }
   }
   gemm2x_kernel<LAYOUT, EPI><<<dim3(grid), T2, LDS2, s>>>(b);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(256x128)");

@@ -115,6 +115,6 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int base, int ks, int
 }  // namespace gemmc
 
 // host side of the scheduler / launch geometry (gemm.hip)
-uint32_t* crl_sched_slot();     // zeroed 16-word state for one persistent launch (rotating pool in device memory), nullptr on error
+uint32_t* crl_sched_slot(hipStream_t stream, bool* ok);     // zeroed 16-word state for one persistent launch (rotating pool in device memory owned by the first stream that asks; nullptr = walk statically)
 int crl_gemm_cus();             // CUs the persistent kernels spread over: 256 minus crl_gemm_set_reserved_cus
 bool crl_gemm_dynamic();        // crl_gemm_set_schedule: dynamic tile tickets (default) or the static walk

@@ -14,8 +14,14 @@ collectives -- rather than DDP's 25 MiB.
 The collectives are issued through torch.distributed (backend "nccl" = RCCL), as the reference's DDP does: stream, channel count and
 event chaining are ProcessGroupNCCL's.  RCCL's kernels hold CUs while a bucket is in flight; the persistent GEMMs cope by pulling
 their tiles from ticket counters (include/crl.h crl_gemm_set_schedule), so a launch that finds CUs taken slows down by about the CU
-fraction.  PIXPARSE_AMD_RCCL_CUS=n additionally makes them launch on 256 - n CUs from the first bucket of a backward sweep until
-finish() (a whole number of tile rounds on the CUs that are left; worth it only when the collectives are long -- default 0, unset).
+fraction.  On top of that the persistent GEMMs launch on 256 - n CUs from the first bucket of a backward sweep until finish() (a whole
+number of tile rounds on the CUs that are left: measured on one GPU with 16 / 32 CUs taken, +6.9 / +7.6 % per step against +13 / +15 %
+without the reservation, profiles/r3_cu_contention.txt).  n = PIXPARSE_AMD_RCCL_CUS when set (0 switches the reservation off); otherwise,
+whenever world_size > 1, NCCL_MAX_NCHANNELS when that is set (RCCL runs one workgroup = one CU per channel), else 16.
+
+Diagnosis of a multi-GPU run (bench.py puts it on its JSON line): `stats()` returns the bucket geometry, the CUs reserved and
+`comm_exposed_ms` -- per optimiser step, the time the compute stream spends in finish() waiting for collectives that have not
+completed when backward is done (event before the first wait -> event after the last one; 0 when everything overlapped).
 """
 import os
 from typing import List, Optional, Tuple
@@ -43,8 +49,32 @@ class BucketedGradReducer:
         self.enabled = True
         self._next = 0
         self._works = []
-        self.reserved_cus = int(os.environ.get('PIXPARSE_AMD_RCCL_CUS', '0') or 0) if arena.p.is_cuda else 0
+        self.bucket_bytes = int(bucket_bytes)
+        self.reserved_cus = self._auto_reserved_cus() if arena.p.is_cuda else 0
         self._reserved_on = False
+        self._exposed = []             # (event before the first wait, event after the last) of every finish() since reset_stats()
+        self._finishes = 0
+
+    def _auto_reserved_cus(self) -> int:
+        env = os.environ.get('PIXPARSE_AMD_RCCL_CUS')
+        if env not in (None, ''):
+            return max(0, int(env))
+        if not (self.active and self.world_size > 1):
+            return 0
+        ch = os.environ.get('NCCL_MAX_NCHANNELS')
+        n = int(ch) if ch and ch.isdigit() and int(ch) > 0 else 16
+        return min(n, 64)
+
+    def reset_stats(self):
+        self._exposed = []
+        self._finishes = 0
+
+    def stats(self) -> dict:
+        """call after a device synchronisation (reads event timings)"""
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        return {'buckets': len(self.buckets), 'bucket_bytes': self.bucket_bytes, 'reserved_cus': self.reserved_cus, 'reductions': self._finishes,
+                'comm_exposed_ms': round(sum(ms) / max(1, len(ms)), 3) if ms else 0.0,
+                'comm_exposed_ms_max': round(max(ms), 3) if ms else 0.0}
 
     def _reserve(self, on: bool):
         if self.reserved_cus and on != self._reserved_on:
@@ -76,8 +106,17 @@ class BucketedGradReducer:
 
     def finish(self):
         self._fire_until(0)
+        timed = self.active and self.enabled and self._works and self.arena.g.is_cuda and len(self._exposed) < 4096
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
+        if self._works:
+            self._finishes += 1
         self._works = []
         self._reserve(False)
 

@@ -25,6 +25,9 @@ SIGNATURES = {
     'crl_gemm_ws_bytes': (Z, [I, I, L, L, L]),
     'crl_gemm_set_policy': (I, [I]),
     'crl_gemm_set_quant_cost': (I, [F]),
+    'crl_gemm_calibrate_ws_bytes': (Z, []),
+    'crl_gemm_calibrate': (I, [P, Z, P]),
+    'crl_gemm_model': (I, [P, P, P]),
     'crl_gemm_set_schedule': (I, [I]),
     'crl_gemm_set_reserved_cus': (I, [I]),
     'crl_gemm_bf16': (I, [I, I, L, L, L, P, L, P, L, P, P, L, P, L, P, L, F, L, P, Z, P]),

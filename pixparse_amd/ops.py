@@ -43,6 +43,28 @@ def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: in
              _p(resid), ldr, float(colscale), int(colscale_cols), _p(ws), wsb, _stream())
 
 
+_calibrated = {}
+
+
+def gemm_calibrate(device, force: bool = False):
+    """one-off per process and device: refit the wave-quantisation cost model of the persistent GEMMs to what THIS device sustains
+    (crl_gemm_calibrate; synchronises).  PIXPARSE_AMD_GEMM_CALIBRATE=0 keeps the built-in constants.  Returns (a_us, b_us, calibrated)."""
+    import ctypes
+    import os
+    key = str(device)
+    if (key not in _calibrated or force) and os.environ.get('PIXPARSE_AMD_GEMM_CALIBRATE', '1') != '0':
+        nbytes = hip.query('crl_gemm_calibrate_ws_bytes')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)      # its own buffer: released again right away
+        rc = hip.load().crl_gemm_calibrate(_p(ws), nbytes, _stream())
+        if rc < 0:
+            raise hip.HipLibraryError(f'crl_gemm_calibrate failed ({rc}): {hip.last_error()}')
+        del ws
+        _calibrated[key] = rc
+    a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+    hip.call('crl_gemm_model', ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c))
+    return a.value, b.value, bool(c.value)
+
+
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int = EPI_BF16,
                aux: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, n: Optional[int] = None,
                colscale: float = 1.0, colscale_cols: int = 0) -> None:
@@ -98,15 +120,27 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate
 
 
 class Scratch:
-    """lazily grown device scratch shared by the reductions (never read across calls)."""
+    """lazily grown device scratch shared by the reductions (never read across calls).  Once a hipGraph has been captured
+    (freeze_scratch()) a buffer that has to grow is RETIRED, not freed: the graph's launches keep writing their slabs / partials into
+    the address they were captured with, which stays owned by this object instead of going back to the caching allocator where other
+    tensors would be handed the same memory."""
+    frozen = False
 
     def __init__(self):
         self.buf = None
+        self.retired = []
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            if Scratch.frozen and self.buf is not None:
+                self.retired.append(self.buf)
             self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         return self.buf
+
+
+def freeze_scratch() -> None:
+    """call before capturing launches into a hipGraph: from now on scratch buffers are never released (see Scratch)"""
+    Scratch.frozen = True
 
 
 _scratch = Scratch()
@@ -204,8 +238,17 @@ def embed_decode(ids, tok, pos, out, step: torch.Tensor, pos_offset: int = 2) ->
              _stream())
 
 
+_attn_mode_env_applied = False
+
+
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, causal: bool, drop=None, site: int = 0,
              q_prescaled: bool = False) -> None:
+    global _attn_mode_env_applied
+    if not _attn_mode_env_applied:      # A/B switch: PIXPARSE_AMD_ATTN_BWD_MODE=1 forces the two-pass backward, 2 the single pass (crl_attn_bwd_set_mode)
+        import os
+        _attn_mode_env_applied = True
+        if os.environ.get('PIXPARSE_AMD_ATTN_BWD_MODE'):
+            hip.call('crl_attn_bwd_set_mode', int(os.environ['PIXPARSE_AMD_ATTN_BWD_MODE']))
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)

@@ -34,6 +34,9 @@ def generate_string(model, tokenizer, encoder_output: torch.Tensor, prompt: str,
     max_pos = model.max_length
     cap = min(max_pos, len(ids) + max_steps + 1)
 
+    if len(ids) >= cap:                               # a prompt that already fills the learned positions: nothing can be generated
+        return current
+
     def restart(seq: List[int]):
         model.decode_begin(enc, cap)
         if len(seq) > 1:

@@ -149,6 +149,9 @@ class TaskCrullerPretrain(TaskTrain):
                                            warmup_t=self.num_warmup_intervals * self.num_steps_per_interval,
                                            warmup_lr_init=opt.warmup_learning_rate)
         self.scheduler.step_update(0)
+        # the persistent GEMMs' wave-quantisation model is refitted to what THIS device sustains (one-off, ~20 ms; PIXPARSE_AMD_GEMM_CALIBRATE=0: built-in)
+        from .. import ops as _ops
+        self.gemm_model = _ops.gemm_calibrate(self.device_env.device)
         # hipGraph replay of the micro-step: legal when nothing the step launches depends on host state -- the LR and the bias
         # corrections come from device words (crl_optim_prepare), the GradScaler lives on the device, batches are copied into static buffers
         import os
@@ -218,6 +221,8 @@ class TaskCrullerPretrain(TaskTrain):
             return loss
         if st == 'warm':
             torch.cuda.synchronize()
+            from .. import ops
+            ops.freeze_scratch()       # the capture bakes scratch addresses into the graph: they must stay owned by the scratch objects
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self.forward(gi, gt, gy)

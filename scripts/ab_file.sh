@@ -1,12 +1,12 @@
 #!/bin/bash
-export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 # same-box A/B of the whole train step: committed (HEAD) version vs working-tree version of ONE csrc file
 #   gpurun -- 'bash scripts/ab_file.sh gemm.hip'       (run `git show HEAD:pixparse_amd/csrc/<file> > pixparse_amd/csrc/<file>.head` first: .git does not travel)
 cd "$(dirname "$0")/.."
+source scripts/_ab_common.sh
 C=pixparse_amd/csrc
 F=$1
 OBJ=$C/${F%.*}.o
-EXTRA=""; [ "$F" = attention.hip ] && EXTRA="-fno-slp-vectorize"
+EXTRA="$(extra_flags $F)"
 for v in head tree head tree; do
   if [ $v = head ]; then cp $C/$F.head $C/_ab_$F; else cp $C/$F $C/_ab_$F; fi
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA -c $C/_ab_$F -o $OBJ || exit 1

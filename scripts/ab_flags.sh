@@ -1,11 +1,11 @@
 #!/bin/bash
 # same-box A/B of the whole train step for compile-time knobs of ONE csrc file:  ab_flags.sh attention.hip "-DFWD_OCC=4" "-DFWD_OCC=3" ...
 cd "$(dirname "$0")/.."
-export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
+source scripts/_ab_common.sh
 C=pixparse_amd/csrc
 F=$1; shift
 OBJ=$C/${F%.*}.o
-EXTRA=""; [ "$F" = attention.hip ] && EXTRA="-fno-slp-vectorize"
+EXTRA="$(extra_flags $F)"
 for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA $flags -c $C/$F -o $OBJ || exit 1
   hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libcruller_hip.so $(ls $C/*.o | tr "\n" " ") || exit 1

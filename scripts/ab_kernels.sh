@@ -1,13 +1,13 @@
 #!/bin/bash
-export PIXPARSE_AMD_SKIP_BUILD_CHECK=1   # objects are rebuilt by hand below, with other flags than build.py records
 # same-box A/B of compile-time knobs of ONE csrc file on the kernel micro-benchmarks:
 #   ab_kernels.sh gemm2x.hip gemm2x "pol=3" "-DG2X_STAGGER=0" "-DG2X_STAGGER=1"
 # (file, scripts/bench_kernels.py mode, grep pattern, flag sets...)
 cd "$(dirname "$0")/.."
+source scripts/_ab_common.sh
 C=pixparse_amd/csrc
 F=$1; MODE=$2; PAT=$3; shift 3
 OBJ=$C/${F%.*}.o
-EXTRA=""; [ "$F" = attention.hip ] && EXTRA="-fno-slp-vectorize"
+EXTRA="$(extra_flags $F)"
 OBJS=$(ls $C/*.o | tr '\n' ' ')
 for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA $flags -c $C/$F -o $OBJ || exit 1

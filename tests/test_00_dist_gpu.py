@@ -53,6 +53,12 @@ def test_bench_under_torchrun_single_rank_takes_rccl_path():
     assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(lines[-1])
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['config']['parallelism'] == 'dp1' and d.get('collectives') == 'rccl'
+    # the diagnosis of a multi-GPU run rides on the same line: bucket geometry, CUs reserved for RCCL, exposed
+    # communication per optimiser step with min / max over the ranks, per-rank step time
+    c = d['comm']
+    assert c['buckets'] >= 1 and c['bucket_bytes'] == 64 << 20 and c['reductions'] == d['steps'] and c['reserved_cus'] == 0     # one rank: nothing to reserve
+    assert c['comm_exposed_ms'] >= 0.0 and c['comm_exposed_ms_max'] >= c['comm_exposed_ms_min'] >= 0.0
+    assert c['step_ms_max'] >= c['step_ms_min'] > 0.0 and abs(c['step_ms_max'] - d['ms_per_step']) < 0.02
 
 
 def test_dp2_on_shared_gpu_equals_grad_accum_2(tmp_path):

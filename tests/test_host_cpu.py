@@ -374,6 +374,32 @@ def _reducer_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_reducer_reserves_cus_for_rccl_by_itself(monkeypatch):
+    """world_size > 1 switches the CU reservation of the persistent GEMMs on without anybody setting a variable: NCCL_MAX_NCHANNELS CUs
+    when RCCL's channel count is pinned, else 16; PIXPARSE_AMD_RCCL_CUS overrides (0 = off); one rank reserves nothing.  stats() carries
+    the bucket geometry bench.py prints."""
+    from types import SimpleNamespace
+    from pixparse_amd.framework.reducer import BucketedGradReducer
+
+    def make(world, active=None):
+        arena = SimpleNamespace(total=50_000_000, p=SimpleNamespace(is_cuda=False), g=None, entries={})
+        r = BucketedGradReducer(arena, world, active=active)
+        return r
+    for k in ('PIXPARSE_AMD_RCCL_CUS', 'NCCL_MAX_NCHANNELS'):
+        monkeypatch.delenv(k, raising=False)
+    assert make(8)._auto_reserved_cus() == 16 and make(1)._auto_reserved_cus() == 0 and make(1, active=True)._auto_reserved_cus() == 0
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '32')
+    assert make(8)._auto_reserved_cus() == 32
+    monkeypatch.setenv('PIXPARSE_AMD_RCCL_CUS', '0')
+    assert make(8)._auto_reserved_cus() == 0
+    monkeypatch.setenv('PIXPARSE_AMD_RCCL_CUS', '24')
+    assert make(8)._auto_reserved_cus() == 24 and make(1)._auto_reserved_cus() == 24
+    r = make(8)
+    assert r.reserved_cus == 0                    # a CPU arena never touches the GEMM launch geometry
+    st = r.stats()
+    assert st['buckets'] == 3 and st['bucket_bytes'] == 64 << 20 and st['comm_exposed_ms'] == 0.0 and st['reductions'] == 0
+
+
 def test_bucketed_reducer_two_gloo_ranks():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
