@@ -401,11 +401,14 @@ def main():
             # (shape key of scripts/pmc_traffic.py: grid = query tiles x B x H workgroups of 256 threads -- for the dK/dV pass the grid of
             # the dQ pass launched right before it) next to that shape's algorithmic bytes (each operand once)
             grid, algo = None, None
-            if m.enc_kind == 'vit' and live_prof['kernel'] in ('attn_fwd_pre_kernel<false>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dq_kernel<false>'):
+            if m.enc_kind == 'vit' and live_prof['kernel'] in ('attn_fwd_pre_kernel<false>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dq_kernel<false>', 'attn_bwd_spx_kernel'):
                 enc_ = m._engines[0]
-                tiles = (enc_.N + 127) // 128
+                spx = live_prof['kernel'] == 'attn_bwd_spx_kernel'      # workgroups of 256 keys instead of 128-row tiles
+                tiles = (enc_.N + 255) // 256 if spx else (enc_.N + 127) // 128
                 grid = tiles * args.batch * enc_.heads * 256
-                n_operands = {'attn_fwd_pre_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6}[live_prof['kernel']]
+                # each operand once: q, k, v, dO in, dK, dV out -- and for the single pass dQ, whose per-key-block bf16 partials (ceil(N / 256)
+                # slabs the size of dQ, summed by attn_dq_reduce_kernel) are the price of one recomputation instead of two: they are NOT algorithmic
+                n_operands = {'attn_fwd_pre_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6, 'attn_bwd_spx_kernel': 7}[live_prof['kernel']]
                 algo = n_operands * args.batch * enc_.N * enc_.D * 2
             traffic, src = pmc_traffic(live_prof['kernel'], grid)
             if traffic is not None:

@@ -2,6 +2,8 @@
 # PMC passes over the attention micro-benchmark (scripts/bench_kernels.py attn: B 8, H 16, N 6189, d 64, random data): effective clock,
 # matrix-pipe busy cycles, VALU issue, co-execution, LDS activity / bank conflicts -- one rocprofv3 run per counter group (no trace domains).
 R=$GRAFT_REPO_ROOT
+TAG=${1:-r3}
+export TAG
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -17,9 +19,10 @@ for f in glob.glob('gpurun_out/pmc_attn_*/**/*counter_collection.csv', recursive
     for r in csv.DictReader(open(f)):
         n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']).replace('void ', '').split('(')[0]
         if not n.startswith('attn'): continue
-        if int(r['Grid_Size']) != 6272 * 256: continue
+        if int(r['Grid_Size']) not in (6272 * 256, 3200 * 256) and not n.startswith('attn_dq_reduce'): continue     # ViT-shape launches: 128-row tiles / 256-key blocks x 128 heads
         agg[n][r['Counter_Name']].append(float(r['Counter_Value']))
-with open('gpurun_out/r3_pmc_attention.txt', 'w') as out:
+import os
+with open('gpurun_out/%s_pmc_attention.txt' % os.environ.get('TAG', 'r3'), 'w') as out:
     for n, c in sorted(agg.items()):
         line = f'{n}: ' + '  '.join(f'{k}={sum(v) / len(v):.4g} (n={len(v)})' for k, v in sorted(c.items()))
         print(line); out.write(line + '\n')
