@@ -347,11 +347,16 @@ static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
 #ifndef G_FEW_TILES_MIN_NK
 #define G_FEW_TILES_MIN_NK 16     // 128 = the first form of the rule, 32 the second (A/B)
 #endif
+static bool slab_epilogue(int epilogue) {
+  return epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID || epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC;
+}
 static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
-  if (layout == CRL_TN || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
+  if (layout == CRL_TN || !slab_epilogue(epilogue) || (K % 64) != 0) return 1;
   const int64_t nk = K / 64, tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  if (nk < G_FEW_TILES_MIN_NK || tiles >= 128) return 1;
-  int ns = (int)(384 / tiles);
+  // round 4: 128 ... 255 tiles (a quarter to a half of the 512 workgroup slots) with a long contraction are cut in two or three as well
+  // (cfg-2: the decoder's 4088-row GEMMs, 192 tiles)
+  if (nk < G_FEW_TILES_MIN_NK || tiles >= 256 || (tiles >= 128 && nk < 64)) return 1;
+  int ns = (int)((tiles >= 128 ? 512 : 384) / tiles);
   if (ns > 32) ns = 32;
   while (ns > 1 && nk / ns < 4) --ns;       // slabs of >= 4 K tiles
   return ns;
@@ -518,6 +523,19 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk reduce)");
     return 0;
   }
+  // slabs of a cut contraction -> C with the epilogue applied (plain fp32 store / accumulate, or bias + bf16 / bias + residual)
+  auto reduce_slabs = [&](const GemmArgs& full, int nsl, const char* what) -> int {
+    const size_t n4 = (size_t)M * N / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC)
+      splitk_reduce_kernel<<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (float*)full.C, (int)M, (int)N, (int)ldc, epilogue == CRL_EPI_F32_ACC);
+    else if (epilogue == CRL_EPI_BF16)
+      splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, full.bias, full.C, (int)ldc, nullptr, 0, full.colscale, full.colscale_cols);
+    else
+      splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, full.bias, full.C, (int)ldc, full.resid, (int)ldr);
+    CRL_LAUNCH_CHECK(what);
+    return 0;
+  };
   if (p.big) {
     const int64_t best_r = quant_rows(layout, epilogue, M, N, K);
     if (best_r < 0) return crl_gemm256_launch(layout, epilogue, a, 1, s);
@@ -566,13 +584,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
       sl.kchunk = (int)((K / 64 + ns - 1) / ns);
       const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
       if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
-      const unsigned blocks = (unsigned)(((size_t)M * N / 4 + 255) / 256);
-      if (epilogue == CRL_EPI_BF16)
-        splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
-      else
-        splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)M * N, (int)M, (int)N, a.bias, a.C, (int)ldc, a.resid, (int)ldr);
-      CRL_LAUNCH_CHECK("crl_gemm_bf16(few-tiles split reduce)");
-      return 0;
+      return reduce_slabs(a, nsl, "crl_gemm_bf16(few-tiles split reduce)");
     }
   }
   switch (layout) {

@@ -508,6 +508,32 @@ def test_gemm_few_tiles_long_contraction_split(dev):
     close(y, want, 1e-2, 3e-2, 'few-tiles split NT + residual')
 
 
+def test_gemm_quarter_full_chip_long_contraction_split(dev):
+    """round 4: the few-tiles split of the 128x128 kernel also covers 128 ... 255 output tiles (a quarter to a half of the chip's 512
+    workgroup slots) when the contraction is long (>= 64 K tiles): cfg-2's 4088-row decoder GEMMs are 192 tiles.  And it now serves the
+    plain fp32 store / accumulate epilogues (dgrads into an fp32 gradient) next to bias + bf16 and bias + residual."""
+    from pixparse_amd import hip, ops
+    M, N, K = 2000, 1536, 4096                     # 16 x 12 = 192 tiles (48 tiles of 256^2 are too few for the big kernel), 64 K tiles -> 2 slabs
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, K) == 2 * M * N * 4
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, 2048) == 0             # 32 K tiles: one launch
+    assert hip.query('crl_gemm_ws_bytes', hip.NN, hip.EPI_F32, 254, 768, 50304) == 32 * 254 * 768 * 4
+    dy = rnd((M, K), dev, 1.0, 7, BF16)
+    w = rnd((K, N), dev, 0.02, 8, BF16)
+    ref = dy.float() @ w.float()
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_dgrad(dy, w, out)
+    close(out, ref, 1e-2, 3e-2, '192-tile split NN bf16')
+    o32 = torch.full((M, N), 0.5, device=dev)
+    ops.gemm(hip.NN, hip.EPI_F32, M, N, K, dy, dy.stride(0), w, w.stride(0), o32, N)
+    close(o32, ref, 2e-3, 2e-2, '192-tile split NN fp32')
+    ops.gemm(hip.NN, hip.EPI_F32_ACC, M, N, K, dy, dy.stride(0), w, w.stride(0), o32, N)
+    close(o32, 2 * ref, 2e-3, 4e-2, '192-tile split NN fp32 accumulate')
+    o32b = torch.full((M, N), 0.5, device=dev)
+    ops.gemm(hip.NN, hip.EPI_F32, M, N, K, dy, dy.stride(0), w, w.stride(0), o32b, N)
+    ops.gemm(hip.NN, hip.EPI_F32_ACC, M, N, K, dy, dy.stride(0), w, w.stride(0), o32b, N)
+    assert torch.equal(o32, o32b), 'slab reduction must be deterministic'
+
+
 def test_gemm_256_splitk_wgrad(dev):
     from pixparse_amd import hip, ops
     Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
