@@ -329,6 +329,7 @@ def scalar_tail():
 #   exp mul cvt dsread dswrite dma store barrier addr salu
 DROP = set(filter(None, os.environ.get('SPX_DROP', '').split(',')))
 OPTS = dict(kv.split('=') if '=' in kv else (kv, '1') for kv in filter(None, os.environ.get('SPX_OPTS', '').split(',')))
+BARRIER_AT = int(OPTS.get('barrier_at', 0))     # number of MFMAs of a pass issued before its wait + s_barrier (0 = at the top)
 STAMPS = 'stamps' in OPTS     # diagnostic build (-DSPX_STAMPS): six s_memtime stamps per pass, written to a trace by scalar stores
 STAMP_AT = {19: 2, 39: 3, 59: 4}  # after MFMA n -> stamp k   (0: after the wait at the top, 1: after the barrier, 5: end of the pass)
 in_loop = [False]
@@ -489,20 +490,26 @@ def generate():
             G.put(72 + 2 * k, ins)
         # the slab offset advances BEFORE this pass's stores (they come in the last gaps): it starts two tiles back
         G.put(1, salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
-        # top of the pass: tile t + 1 landed (the two slab stores of the previous pass may still be in flight), this wave's dS
-        # stores and every LDS read of the previous pass are complete
-        H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
-        if STAMPS:
-            # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
-            H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
-                           '\n\ts_add_u32 %[s_dbgoff], %[s_dbgoff], 8\n\ts_memtime %[st0]', 'salu'))
-        E(I('s_barrier', 'barrier'))
-        if STAMPS:
-            H.out.append(I('s_memtime %[st1]', 'salu'))
+        # the pass's rendezvous: tile t + 1 landed (the two slab stores of the previous pass may still be in flight), this wave's dS stores and
+        # every LDS read of the previous pass are complete.  It sits BEHIND the first BARRIER_AT MFMAs of the pass (S / dP of the next block from
+        # operands already in registers; their gaps hold VALU work only), so the wait overlaps matrix work instead of draining the pipe.
+        def rendezvous():
+            H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
+            if STAMPS:
+                # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
+                H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
+                               '\n\ts_add_u32 %[s_dbgoff], %[s_dbgoff], 8\n\ts_memtime %[st0]', 'salu'))
+            E(I('s_barrier', 'barrier'))
+            if STAMPS:
+                H.out.append(I('s_memtime %[st1]', 'salu'))
+        if BARRIER_AT == 0:
+            rendezvous()
         for i, m in enumerate(bb):
             E(m)
             for ins in G.g[i]:
                 E(ins)
+            if i + 1 == BARRIER_AT:
+                rendezvous()
             if STAMPS and i in STAMP_AT:
                 H.out.append(I(f's_memtime %[st{STAMP_AT[i]}]', 'salu'))
         if STAMPS:
