@@ -165,8 +165,8 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
  *               ceil(Nk / 256) slabs in fixed order in fp32, applies `scale` and rounds to dq.  With q_prescaled the kernel is one
  *               hand-placed instruction stream (csrc/gen_attn_bwd_sp.py); without, the C++ form of the same algorithm (slow: tests).
  * crl_attn_bwd_ws_bytes: 0 when the two-pass form will run.
- * crl_attn_bwd_set_mode: 0 = auto: single pass for non-causal problems with Nq >= 2048, Nk >= 1024 and a prescaled q (the ViT encoders:
- *   same-box 3.29 against 3.65 ms per layer at B 8, H 16, N 6189), two-pass otherwise; 1 = two-pass; 2 = single pass whenever legal
+ * crl_attn_bwd_set_mode: 0 = auto: single pass for non-causal problems with Nq >= 1000, Nk >= 1024 and a prescaled q (the ViT encoders:
+ *   same-box 3.22 against 3.51 ms per layer at B 8, H 16, N 6189; cross-attention 1023 x 6189: 0.63 against 0.67), two-pass otherwise; 1 = two-pass; 2 = single pass whenever legal
  *   (non-causal); 3 = single pass in its C++ form (reference of the hand-placed stream: bit-identical results). */
 size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
 int crl_attn_bwd_set_mode(int mode);

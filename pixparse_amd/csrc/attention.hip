@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
   uint32_t sqv = sq.v, sdov = sdo.v, rcv = (uint32_t)lane * 4u;
   uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 8 * hh) * 2);   // 16 bytes per lane (the stream swaps lane halves)
-  uint32_t dkv = (uint32_t)(((int64_t)(key0 + ki) * a.dk_rs + 4 * hh) * 2), dvv = (uint32_t)(((int64_t)(key0 + ki) * a.dv_rs + 4 * hh) * 2);
+  uint32_t dkv = (uint32_t)(((int64_t)(key0 + ki) * a.dk_rs + 8 * hh) * 2), dvv = (uint32_t)(((int64_t)(key0 + ki) * a.dv_rs + 8 * hh) * 2);   // 16 bytes per lane
   const int kr0 = min(key0 + ki, a.Nk - 1), kr1 = min(key0 + 32 + ki, a.Nk - 1);
   uint32_t koff0 = (uint32_t)(((int64_t)kr0 * a.k_rs + 8 * hh) * 2), koff1 = (uint32_t)(((int64_t)kr1 * a.k_rs + 8 * hh) * 2);
   uint32_t voff0 = (uint32_t)(((int64_t)kr0 * a.v_rs + 8 * hh) * 2), voff1 = (uint32_t)(((int64_t)kr1 * a.v_rs + 8 * hh) * 2);
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const uint32_t s_q32 = (uint32_t)(32 * a.q_rs * 2), s_do32 = (uint32_t)(32 * a.do_rs * 2);
   const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
   const float s_dkscale = a.scale;
-  const uint32_t s_iters = (uint32_t)nqt64 + 1u;   // the last pass only finishes dQ of the last tile (its other products see zero rows)
+  const uint32_t s_iters = (uint32_t)nqt64;        // + the drain behind the loop: dV / dK of the last block, dQ of the last tile
   // running state: the DMA of pass t fetches tile t + 2; the slab offset advances before the stores of a pass (tile t - 1)
   uint32_t s_qoff = 2u * s_qstep, s_dooff = 2u * s_dostep, s_rcoff = 2u * 256u, s_slaboff = (uint32_t)(-2 * (int)s_slabstep);
   const uint32_t s_m0q = sbase + wave * 1024, s_m0rc = sbase + 16384 + wave * 256;     // + ring slot + piece: immediates of the unrolled passes
@@ -1145,11 +1145,12 @@ extern "C" int crl_attn_bwd_set_mode(int mode) {
   g_bwd_mode = mode;
   return 0;
 }
-// auto: the single pass pays from a few dozen query tiles per workgroup on (its prologue / epilogue -- K^T fragments, 128 accumulators in
-// and out -- cost as much as ~6 tile passes): the ViT encoders (N = 2401 ... 24 935), not the decoder's cross-attention (Nq = 1023)
+// auto: the single pass pays from about sixteen query tiles per workgroup on (its prologue / epilogue -- K^T fragments, 128 accumulators
+// in and out -- cost as much as ~5 tile passes): the ViT encoders (N = 2401 ... 24 935) and the decoder's cross-attention at cfg-3
+// (Nq = 1023: 0.63 against 0.67 ms per layer), not short target sequences
 static bool bwd_fused_wanted(int Nq, int Nk, int causal) {
   if (causal || g_bwd_parts != 7) return false;
-  return g_bwd_mode >= 2 || (g_bwd_mode == 0 && Nq >= 2048 && Nk >= 1024);
+  return g_bwd_mode >= 2 || (g_bwd_mode == 0 && Nq >= 1000 && Nk >= 1024);
 }
 // bf16 partial-dQ slabs of the fused backward: ceil(Nk / 256) x [B, Nq, H * 64]; 0 = the two-pass form runs (no workspace needed)
 extern "C" size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal) {

@@ -516,8 +516,36 @@ def generate():
             H.out.append(I('s_memtime %[st5]', 'salu'))
         E(salu(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1'))
         E(salu(f's_cmp_eq_u32 {op("s_cnt")}, 0'))
-        E(I('s_cbranch_scc1 DONE%=' if p < 5 else 's_cbranch_scc0 LOOP%=', 'branch'))
+        E(I(f's_cbranch_scc1 DRAIN{p & 1}%=', 'branch'))
+        if p == 5:
+            E(I('s_branch LOOP%=', 'branch'))
     in_loop[0] = False
+    # ================================================================= drain: what the pass after the last tile would still have to do --
+    # dV / dK of the last block (operands are in registers) and dQ of the last tile -- without the 56 MFMAs and the VALU work it would
+    # spend on a tile of zero rows.  The pass that follows pass p reads the dS buffer of parity p & 1: one copy per parity.
+    for par in range(2):
+        H.out.append(I(f'DRAIN{par}%=:', 'label'))
+        H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
+        E(I('s_barrier', 'barrier'))
+        E(salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
+        H.settle_mfma()                       # the S / dP results of the last pass are not read any more
+        for ins in load_dsf(0, par):
+            E(ins)
+        for m in m2_block(1):
+            E(m)
+        for w in range(4):                    # one quarter of dS^T at a time (the fragment registers are shared); once per workgroup
+            if w:
+                for ins in load_dsf(w, par):
+                    E(ins)
+            for m in dq_quarter(w):
+                E(m)
+        E(I('s_nop 7\n\ts_nop 7', 'nop'))
+        H.settle_mfma()
+        cv, st = dq_store()
+        for ins in cv + st:
+            E(ins)
+        if par == 0:
+            E(I('s_branch DONE%=', 'branch'))
     H.out.append(I('DONE%=:', 'label'))
     G = Gs[0]
     # ================================================================= epilogue: dK (scaled), dV -> bf16 -> bounds-checked stores
@@ -531,18 +559,22 @@ def generate():
         for kb in range(2):
             for db in range(2):
                 acc = abase + 16 * (2 * kb + db)
-                for g in range(4):
+                for g in (0, 2):              # groups g, g + 1 -> bf16 -> exchanged between the lane halves -> one 16-byte store per lane
                     r = tmp
-                    tmp = (tmp + 6) % 216
-                    for j in range(4):
+                    tmp = (tmp + 8) % 216
+                    for j in range(8):
                         E(valu(f'v_accvgpr_read_b32 v{r + j}, a{acc + 4 * g + j}', [f'a{acc + 4 * g + j}'], [f'v{r + j}']))
                     if which == 'dk':
-                        for j in range(4):
+                        for j in range(8):
                             E(valu(f'v_mul_f32 v{r + j}, {op("s_dkscale")}, v{r + j}', [f'v{r + j}'], [f'v{r + j}']))
-                    E(v_cvt(r + 4, r, r + 1))
-                    E(v_cvt(r + 5, r + 2, r + 3))
+                    E(v_cvt(r, r, r + 1))
+                    E(v_cvt(r + 1, r + 2, r + 3))
+                    E(v_cvt(r + 2, r + 4, r + 5))
+                    E(v_cvt(r + 3, r + 6, r + 7))
+                    E(valu(f'v_permlane32_swap_b32 v{r}, v{r + 2}', [f'v{r}', f'v{r + 2}'], [f'v{r}', f'v{r + 2}'], kind='perm'))
+                    E(valu(f'v_permlane32_swap_b32 v{r + 1}, v{r + 3}', [f'v{r + 1}', f'v{r + 3}'], [f'v{r + 1}', f'v{r + 3}'], kind='perm'))
                     soff = op(s32) if kb else '0'
-                    E(I(f'buffer_store_dwordx2 {vr(r + 4, 2)}, {op(voff)}, {op(srd)}, {soff} offen offset:{64 * db + 16 * g}', 'vmem', reads=regs('v', r + 4, 2)))
+                    E(I(f'buffer_store_dwordx4 {vr(r, 4)}, {op(voff)}, {op(srd)}, {soff} offen offset:{64 * db + 16 * g}\n\ts_nop 1', 'vmem', reads=regs('v', r, 4)))
     return H.out, G
 
 
