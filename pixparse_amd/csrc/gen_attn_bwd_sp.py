@@ -448,6 +448,12 @@ def generate():
     H = Hazards()
     E = H.emit
     # ================================================================= prologue
+    # K / V row fragments of this wave's 64 keys straight into the accumulator file (rows past Nk are clamped to the last key): issued FIRST,
+    # their latency and that of the staging DMA runs under the ~200 register initialisations below
+    for kb in range(2):
+        for ks in range(4):
+            E(I(f'buffer_load_dwordx4 {ar(A_KF + 4 * (4 * kb + ks), 4)}, {op(f"koff{kb}")}, {op("rk")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'koff{kb}']))
+            E(I(f'buffer_load_dwordx4 {ar(A_VF + 4 * (4 * kb + ks), 4)}, {op(f"voff{kb}")}, {op("rv")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'voff{kb}']))
     for i in range(128):
         E(valu(f'v_accvgpr_write_b32 a{i}, 0', [], [f'a{i}']))
     for b in (V_P[0], V_P[1]):
@@ -457,11 +463,6 @@ def generate():
         E(valu(f'v_mov_b32 v{V_TF + i}, 0', [], [f'v{V_TF + i}']))
     for i in range(16):
         E(valu(f'v_mov_b32 v{V_DSF + i}, 0', [], [f'v{V_DSF + i}']))
-    # K / V row fragments of this wave's 64 keys straight into the accumulator file (rows past Nk are clamped to the last key)
-    for kb in range(2):
-        for ks in range(4):
-            E(I(f'buffer_load_dwordx4 {ar(A_KF + 4 * (4 * kb + ks), 4)}, {op(f"koff{kb}")}, {op("rk")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'koff{kb}']))
-            E(I(f'buffer_load_dwordx4 {ar(A_VF + 4 * (4 * kb + ks), 4)}, {op(f"voff{kb}")}, {op("rv")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'voff{kb}']))
     H.drain('s_waitcnt vmcnt(0)')        # K staging, tiles 0 and 1 (issued by the C++ part), the fragments above
     E(I('s_barrier', 'barrier'))
     # K^T fragments [32 d of this wave's d block][256 keys] from the staged K tiles
