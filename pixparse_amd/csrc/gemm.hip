@@ -331,8 +331,11 @@ static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_
 #ifndef G_REM_SPLIT
 #define G_REM_SPLIT 1
 #endif
+static bool slab_epilogue(int epilogue);
 static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
-  if (!G_REM_SPLIT || !(epilogue == CRL_EPI_BF16 || epilogue == CRL_EPI_F32_RESID) || (K % 64) != 0) return 1;
+  // round 4: the fp32 store / accumulate epilogues too -- the 360 remainder rows of the fused cross-attention K/V dgrad (contraction 20 480,
+  // fp32 output) ran 0.4 ms on 24 CUs
+  if (!G_REM_SPLIT || !slab_epilogue(epilogue) || (K % 64) != 0) return 1;
   const int64_t nk = K / 64, tiles = ((rem + 127) / 128) * ((N + 127) / 128);
   if (nk < 32 || tiles >= 128) return 1;
   int ns = (int)(384 / tiles);
@@ -563,7 +566,9 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
       const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
       if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
       const unsigned blocks = (unsigned)(((size_t)rem * N / 4 + 255) / 256);
-      if (epilogue == CRL_EPI_BF16)
+      if (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC)
+        splitk_reduce_kernel<<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (float*)rest.C, (int)rem, (int)N, (int)ldc, epilogue == CRL_EPI_F32_ACC);
+      else if (epilogue == CRL_EPI_BF16)
         splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
       else
         splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, rest.resid, (int)ldr);

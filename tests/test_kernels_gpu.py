@@ -484,6 +484,13 @@ def test_gemm_remainder_rows_split_contraction(dev):
         w2 = rnd((K, N), dev, 0.05, 6, BF16)        # NN: out[M, N] = x[M, K] @ w2[K, N]
         ops.linear_dgrad(x, w2, out)
         close(out, x.float() @ w2.float(), 1e-2, 2e-2, 'remainder split NN')
+        # round 4: the fp32 store / accumulate epilogues take the same route (the fused cross-attention K/V dgrad writes fp32)
+        assert hip.query('crl_gemm_ws_bytes', hip.NN, hip.EPI_F32, M, N, K) > 0
+        o32 = torch.full((M, N), 0.25, device=dev)
+        ops.gemm(hip.NN, hip.EPI_F32, M, N, K, x, x.stride(0), w2, w2.stride(0), o32, N)
+        close(o32, x.float() @ w2.float(), 2e-3, 2e-2, 'remainder split NN fp32')
+        ops.gemm(hip.NN, hip.EPI_F32_ACC, M, N, K, x, x.stride(0), w2, w2.stride(0), o32, N)
+        close(o32, 2 * (x.float() @ w2.float()), 2e-3, 4e-2, 'remainder split NN fp32 accumulate')
 
 
 def test_gemm_few_tiles_long_contraction_split(dev):
