@@ -448,6 +448,8 @@ def generate():
     H = Hazards()
     E = H.emit
     # ================================================================= prologue
+    if STAMPS:
+        H.out.append(I('s_memtime %[st2]', 'salu'))
     # K / V row fragments of this wave's 64 keys straight into the accumulator file (rows past Nk are clamped to the last key): issued FIRST,
     # their latency and that of the staging DMA runs under the ~200 register initialisations below
     for kb in range(2):
@@ -464,6 +466,8 @@ def generate():
     for i in range(16):
         E(valu(f'v_mov_b32 v{V_DSF + i}, 0', [], [f'v{V_DSF + i}']))
     H.drain('s_waitcnt vmcnt(0)')        # K staging, tiles 0 and 1 (issued by the C++ part), the fragments above
+    if STAMPS:
+        H.out.append(I('s_memtime %[st3]', 'salu'))
     E(I('s_barrier', 'barrier'))
     # K^T fragments [32 d of this wave's d block][256 keys] from the staged K tiles
     for kk in range(16):
@@ -473,6 +477,8 @@ def generate():
     for ins in load_seeds(0) + load_qf(0):
         E(ins)
     H.drain('s_waitcnt lgkmcnt(0)')
+    if STAMPS:
+        H.out.append(I('s_memtime %[st4]', 'salu'))
     for m in m1_block(None, 0):          # S / dP of block (tile 0, qb 0, kb 0)
         E(m)
     E(I('s_nop 7\n\ts_nop 7', 'nop'))
@@ -480,7 +486,7 @@ def generate():
     E(salu(f's_mov_b32 {op("s_cnt")}, {op("s_iters")}'))
     # ================================================================= loop, unrolled over six passes (ring of 3 x dS double buffer)
     if STAMPS:
-        H.out.append(I('\n\t'.join(f's_mov_b64 %[st{k}], 0' for k in range(6)), 'salu'))
+        H.out.append(I('s_memtime %[st5]\n\ts_mov_b64 %[st0], 0\n\ts_mov_b64 %[st1], 0', 'salu'))
     H.out.append(I('LOOP%=:', 'label'))
     in_loop[0] = True
     Gs = []

@@ -13,5 +13,5 @@ for v in "$@"; do
   drop="${v%%:*}"; opts=""; [[ "$v" == *:* ]] && opts="${v#*:}"
   build "$drop" "$opts"
   echo "== drop=[$drop] opts=[$opts]"
-  python scripts/check_attn_sp.py --time-only --modes 2 2>&1 | grep "mode 2\|stamps\|trace"
+  python scripts/check_attn_sp.py --time-only --modes 2 2>&1 | grep "mode 2\|stamps\|trace\|prologue"
 done

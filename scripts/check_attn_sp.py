@@ -93,6 +93,13 @@ def stamps(nwg, Nq):
                     continue
                 seg['top wait'].append(s0 - prev_end); seg['barrier'].append(s1 - s0); seg['slot 0'].append(s2 - s1)
                 seg['slot 1'].append(s3 - s2); seg['slot 2'].append(s4 - s3); seg['slot 3'].append(s5 - s4)
+        pro = {k: [] for k in ('wait for DMA / K,V loads', 'K^T + first fragments', 'first S / dP')}
+        for wg in range(64):
+            a, b, c, d = (tr[(k * 65 + wg) * 128 + 0] for k in (2, 3, 4, 5))
+            if min(a, b, c, d) > 0:
+                pro['wait for DMA / K,V loads'].append(b - a); pro['K^T + first fragments'].append(c - b); pro['first S / dP'].append(d - c)
+        if pro['first S / dP']:
+            print('  prologue (cycles, median / max over 64 workgroups of the first round): ' + ', '.join(f'{k} {statistics.median(v):.0f} / {max(v):.0f}' for k, v in pro.items()), flush=True)
         print('  per-pass trace (cycles, median / p90 over 64 workgroups x passes): ' +
               ', '.join(f'{k} {statistics.median(v):.0f} / {sorted(v)[int(len(v) * 0.9)]:.0f}' for k, v in seg.items() if v), flush=True)
 
