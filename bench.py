@@ -410,13 +410,23 @@ def main():
                 # slabs the size of dQ, summed by attn_dq_reduce_kernel) are the price of one recomputation instead of two: they are NOT algorithmic
                 n_operands = {'attn_fwd_pre_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6, 'attn_bwd_spx_kernel': 7}[live_prof['kernel']]
                 algo = n_operands * args.batch * enc_.N * enc_.D * 2
+                shape_note = f'encoder self-attention launches (N = {enc_.N}, grid {grid} threads)'
+                if spx:
+                    # the decoder's cross-attention launches have the SAME grid (ceil(Nk / 256) key blocks x B x H): the PMC mean is over the
+                    # mix of encoder and cross launches, so the algorithmic figure is the mean over the same mix
+                    dec_ = m._engines[1]
+                    cross = (3 * dec_.T + 4 * enc_.N) * args.batch * enc_.D * 2        # q, dO, dQ rows of the targets; k, v, dK, dV rows of the encoder
+                    ne, nd = enc_.a['depth'], dec_.L
+                    algo = (ne * algo + nd * cross) // (ne + nd)
+                    shape_note = (f'mean over the {ne} encoder (N = {enc_.N}) and {nd} cross-attention ({dec_.T} x {enc_.N}) launches of a step, which share one grid; '
+                                  f'the bytes above the algorithmic ones are the ceil(N / 256) bf16 partial-dQ slabs (by design: DESIGN.md (d))')
             traffic, src = pmc_traffic(live_prof['kernel'], grid)
             if traffic is not None:
                 live_prof['traffic'] = traffic
                 live_prof['traffic_source'] = src
                 if algo:
                     live_prof['traffic_algorithmic'] = algo
-                    live_prof['traffic_shape'] = f'encoder self-attention launches (N = {enc_.N}, grid {grid} threads)'
+                    live_prof['traffic_shape'] = shape_note
             elif src:
                 live_prof['traffic_note'] = src
             if env.world_size == 1 and not args.no_peak:
