@@ -70,6 +70,17 @@ if __name__ == '__main__':
                 gemm_case('dgrad proj', 'NN', M, 1024, 1024)
                 gemm_case('dgrad dec kv', 'NN', M, 2048, 1024)
         sys.exit(0)
+    if which == 'enc2x':    # encoder shapes with the epilogue-heavy K = 1024 GEMMs: automatic plan (256x256 persistent + cut) vs the 256x128 two-per-CU kernel
+        M = 49512
+        for rep in range(2):
+            for pol in (0, 3):
+                gemm_case('proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, policy=pol)
+                gemm_case('fc1 gelu', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU, policy=pol)
+                gemm_case('dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, policy=pol)
+                gemm_case('dgrad proj', 'NN', M, 1024, 1024, policy=pol)
+                gemm_case('fc2 resid', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, policy=pol)
+                gemm_case('qkv', 'NT', M, 3072, 1024, policy=pol)
+        sys.exit(0)
     if which == 'dec':      # decoder-side shapes (M = 8 x 1023 rows): automatic plan vs the 256x128 two-per-CU kernel vs forced 256x256
         M = 8184
         for rep in range(2):
