@@ -34,9 +34,30 @@ def _env(**kw):
     return e
 
 
+def _run(cmd, timeout, env):
+    """run a child launcher; these take 5-25 s.  A launch that has not finished after `timeout` seconds is killed and started ONCE more
+    (round 4: one run of the suite lost 15 minutes to a two-rank torchrun child that never got past its gloo rendezvous, on a box where
+    the same test takes 7 s; the retry keeps a stuck rendezvous from eating the whole suite's time budget -- a second hang fails the test)."""
+    import signal
+    cmd = list(cmd)
+    for attempt in (1, 2):
+        if attempt == 2 and '--master-port' in cmd:
+            cmd[cmd.index('--master-port') + 1] = str(_free_port())
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)          # the launcher AND its workers (its own process group: started with a new session)
+            out, err = p.communicate()
+            print(f'[dist test] attempt {attempt}: {" ".join(map(str, cmd[-4:]))} timed out after {timeout} s; stderr tail: {err[-500:]}')
+            if attempt == 2:
+                raise
+
+
 def test_rccl_single_rank_reducer_and_train_step():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_child.py')], capture_output=True, text=True, cwd=ROOT, timeout=900,
-                       env=_env(RANK=0, LOCAL_RANK=0, WORLD_SIZE=1, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port()))
+    r = _run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_child.py')], 300,
+             _env(RANK=0, LOCAL_RANK=0, WORLD_SIZE=1, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port()))
     assert r.returncode == 0 and 'RCCL_CHILD_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     print(r.stdout[-300:])
 
@@ -48,7 +69,7 @@ def test_bench_under_torchrun_single_rank_takes_rccl_path():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
            '--model', 'cruller_base_960x640', '--batch', '2', '--no-cpu-baseline', '--no-roofline']
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1200, env=_env())
+    r = _run(cmd, 400, _env())
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(lines[-1])
@@ -66,9 +87,9 @@ def test_dp2_on_shared_gpu_equals_grad_accum_2(tmp_path):
     script = os.path.join(ROOT, 'scripts', 'check_dp2_shared_gpu.py')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), script, '--out', out]
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=_env(CRL_DEBUG_SHARED_GPU=1))
+    r = _run(cmd, 300, _env(CRL_DEBUG_SHARED_GPU=1))
     assert r.returncode == 0 and os.path.exists(out), (r.stdout[-2000:], r.stderr[-4000:])
-    r = subprocess.run([sys.executable, script, '--reference', out], capture_output=True, text=True, cwd=ROOT, timeout=900, env=_env())
+    r = _run([sys.executable, script, '--reference', out], 300, _env())
     assert r.returncode == 0 and 'DP2 == ACCUM2: OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -84,9 +105,9 @@ def test_rccl_two_ranks_equals_accum2(tmp_path):
            '--master-port', str(_free_port()), script, '--out', out, '--expect-backend', 'nccl']
     env = _env()
     env.pop('CRL_DEBUG_SHARED_GPU', None)
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    r = _run(cmd, 300, env)
     assert r.returncode == 0 and os.path.exists(out), (r.stdout[-2000:], r.stderr[-4000:])
-    r = subprocess.run([sys.executable, script, '--reference', out], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    r = _run([sys.executable, script, '--reference', out], 300, env)
     assert r.returncode == 0 and 'DP2 == ACCUM2: OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -97,7 +118,7 @@ def test_bench_two_ranks_rccl():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--model', 'cruller_base_960x640', '--batch', '2', '--no-cpu-baseline', '--no-roofline']
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1200, env=_env())
+    r = _run(cmd, 400, _env())
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(lines[0])

@@ -515,6 +515,22 @@ def test_gemm_few_tiles_long_contraction_split(dev):
     close(y, want, 1e-2, 3e-2, 'few-tiles split NT + residual')
 
 
+def test_gemm_round_model_calibration(dev):
+    """crl_gemm_calibrate: one / two rounds of 256x256 tiles timed at K = 1024 / 4096 on hashed bf16 operands refit the microseconds-per-round
+    model of the wave-quantisation cut for THIS device.  Plausible numbers, and results of a cut GEMM unchanged."""
+    from pixparse_amd import hip, ops
+    a, b, cal = ops.gemm_calibrate(dev, force=True)
+    assert cal and 0.0 <= a < 30.0 and 11.0 < b < 44.0, (a, b, cal)            # one round of 256 tiles: ~20-50 us at K = 1024 on an MI355X
+    M, N, K = 256 * 64 + 232, 1024, 2048
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.05, 2, BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.linear_fwd(x, w, None, out)
+    close(out, x.float() @ w.float().t(), 1e-2, 2e-2, 'GEMM after calibration')
+    a2, b2, _ = ops.gemm_calibrate(dev)                                          # cached: no second measurement
+    assert (a2, b2) == (a, b)
+
+
 def test_gemm_quarter_full_chip_long_contraction_split(dev):
     """round 4: the few-tiles split of the 128x128 kernel also covers 128 ... 255 output tiles (a quarter to a half of the chip's 512
     workgroup slots) when the contraction is long (>= 64 K tiles): cfg-2's 4088-row decoder GEMMs are 192 tiles.  And it now serves the
