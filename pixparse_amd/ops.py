@@ -52,7 +52,8 @@ def gemm_calibrate(device, force: bool = False):
     import ctypes
     import os
     key = str(device)
-    if (key not in _calibrated or force) and os.environ.get('PIXPARSE_AMD_GEMM_CALIBRATE', '1') != '0':
+    # (two ranks sharing one device -- CRL_DEBUG_SHARED_GPU, a validation aid -- would time each other's launches: built-in constants there)
+    if (key not in _calibrated or force) and os.environ.get('PIXPARSE_AMD_GEMM_CALIBRATE', '1') != '0' and os.environ.get('CRL_DEBUG_SHARED_GPU', '0') != '1':
         nbytes = hip.query('crl_gemm_calibrate_ws_bytes')
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)      # its own buffer: released again right away
         rc = hip.load().crl_gemm_calibrate(_p(ws), nbytes, _stream())
