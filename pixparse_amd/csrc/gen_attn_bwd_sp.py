@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates attn_bwd_sp_body.inc: the hand-placed gfx950 instruction stream of the single-pass attention backward
-(attention.hip: attn_bwd_sp_kernel).  One workgroup = 4 waves = 256 keys of one (batch, head), one wave per SIMD with the whole
+(attention.hip: attn_bwd_spx_kernel; attn_bwd_sp_kernel is the C++ form of the same algorithm, its bit-exact reference).  One workgroup = 4 waves = 256 keys of one (batch, head), one wave per SIMD with the whole
 512-entry register file; the stream is ONE inline-asm statement whose registers are allocated here:
 
   a[0:63]     dV^T accumulators  [kb][db] x 16        a[64:127]   dK^T accumulators
@@ -15,11 +15,18 @@
   v[224:255]  left to the compiler: the per-lane LDS / global offsets it passes in as operands
 
 Per 64-query tile a wave issues 80 MFMAs (32 S / dP, 32 dV / dK, 16 dQ of the PREVIOUS tile) as a fixed backbone; everything else --
-112 LDS instructions, 64 v_exp, 64 multiplies, 72 conversions, 5 LDS-DMA pieces, 4 slab stores, address updates, counted waits -- is
-assigned to one of the 80 MFMA gaps by the tables below.  Software pipeline over 32 x 32 blocks n = (qb, kb):
+112 LDS instructions, 64 v_exp, 64 multiplies, 72 conversions, 5 LDS-DMA pieces, 2 slab stores (16 bytes per lane after a
+v_permlane32_swap exchange), counted waits -- is assigned to one of the 80 MFMA gaps by the tables below.  The loop is unrolled six-fold
+(ring of 3 x dS double buffer): every LDS address of a pass is a per-lane base register + an immediate.  Software pipeline over 32 x 32 blocks n = (qb, kb):
   slot n:  MFMAs  S / dP of block n + 1  |  dV / dK of block n - 1  |  a quarter of dQ(t - 1)     VALU: exp / mul / cvt of block n
 so no MFMA ever waits for VALU work of its own slot.  One s_barrier per tile (top of the iteration): dS of tile t - 1 complete, ring
-slot of tile t - 1 and dS buffer of tile t - 2 free.  Q / dO tiles arrive by LDS-DMA two tiles ahead (ring of 3).
+slot of tile t - 1 and dS buffer of tile t - 2 free.  Q / dO tiles arrive by LDS-DMA two tiles ahead (ring of 3).  Behind the loop a
+drain does what a further pass would still owe (dV / dK of the last block, dQ of the last tile); then dK / dV leave as bf16.
+
+Issue model the placement is priced with (measured: DESIGN.md "Round 4"): a wave alone on its SIMD pays max(32, sum of filler issue
+costs + ~5) cycles per MFMA gap -- v_exp ~8, plain VALU ~5, an LDS instruction ~9; nothing else hides anything.
+Diagnostics: SPX_OPTS=stamps (with -DSPX_STAMPS: six s_memtime stamps per pass + four in the prologue, written out by scalar stores),
+SPX_DROP=class,... (timing-only builds without an instruction class: WRONG results), SPX_OPTS=barrier_at=n; scripts/ab_spx.sh drives them.
 
 The hazard pass below inserts what hipcc does not do for asm: counted s_waitcnt lgkmcnt for every LDS read before its first consumer,
 s_nop between a VALU write and an MFMA read of the same register, and it CHECKS (does not fix) the MFMA-result -> VALU distance.
