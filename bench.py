@@ -336,8 +336,8 @@ def main():
         # per-rank step time and exposed communication: min / max over the ranks tell a straggler from a uniformly slow collective
         mine = torch.tensor([dt, -dt, comm['comm_exposed_ms'], -comm['comm_exposed_ms']], device=env.device, dtype=torch.float64)
         dist.all_reduce(mine, op=dist.ReduceOp.MAX)
-        rank_ms = {'step_ms_min': round(-float(mine[1]) / args.steps * 1e3, 2), 'step_ms_max': round(float(mine[0]) / args.steps * 1e3, 2),
-                   'comm_exposed_ms_min': round(-float(mine[3]), 3), 'comm_exposed_ms_max': round(float(mine[2]), 3)}
+        rank_ms = {'step_ms_rank_min': round(-float(mine[1]) / args.steps * 1e3, 2), 'step_ms_rank_max': round(float(mine[0]) / args.steps * 1e3, 2),
+                   'comm_exposed_ms_rank_min': round(-float(mine[3]), 3), 'comm_exposed_ms_rank_max': round(float(mine[2]), 3)}
         dt = float(mine[0])
     host = None
     if not args.host_inputs and not args.no_host_leg:
@@ -380,14 +380,14 @@ def main():
         'gemm_round_model_us': dict(zip(('a', 'b_per_1024_k', 'calibrated'), getattr(task, 'gemm_model', (None, None, False)))),
         'step_mfma_frac': round(step_tflops / PEAK_BF16_TFLOPS, 4), 'step_tflops_per_gpu': round(step_tflops, 1),
         'activation_gb': round(m.activation_bytes() / 2 ** 30, 2),
-        'collectives': 'rccl' if env.distributed else 'none',
+        'collectives': ({'nccl': 'rccl'}.get(dist.get_backend(), dist.get_backend()) if env.distributed else 'none'),
         'launch': 'hipGraph replay of the micro-step' if getattr(task, '_graph_on', False) else 'eager launches',
     }
     if host is not None:
         out['host_inputs'] = host
     if comm is not None:
         out['comm'] = dict(comm, **(rank_ms or {}), what='bucketed all-reduce of the gradient arena (torch.distributed nccl = RCCL); comm_exposed_ms = per optimiser '
-                           'step, time the compute stream waits in reducer.finish() for collectives still running when backward is done (rank 0; min / max over ranks alongside)')
+                           'step, time the compute stream waits in reducer.finish() for collectives still running when backward is done (rank 0: mean and max over its steps; *_rank_min / *_rank_max: over the ranks)')
     if args.occupy_cus or args.reserved_cus or args.gemm_schedule != 'dynamic':
         out['disturbance'] = {'occupied_cus': args.occupy_cus, 'reserved_cus': args.reserved_cus, 'gemm_schedule': args.gemm_schedule,
                               'what': 'A/B run for the multi-GPU CU-contention experiment (DESIGN.md (e)); not a headline number'}
