@@ -61,6 +61,37 @@ def test_swin_window_attention_is_compiled_to_mfma():
     assert 'ds_read_b64_tr_b16' in fwd and 'ds_read_b64_tr_b16' in bwd
 
 
+def test_attention_backward_stream_is_in_sync_and_its_hazard_pass_bites():
+    """csrc/attn_bwd_sp_body.inc (the hand-placed single-pass attention backward, committed) is exactly what csrc/gen_attn_bwd_sp.py
+    generates today; per 64-query tile pass it holds the 80 MFMAs the design counts, and the generator's hazard pass refuses a schedule
+    that reads an MFMA result too early."""
+    import importlib.util, re
+    from pixparse_amd import build as b
+    spec = importlib.util.spec_from_file_location('gen_attn_bwd_sp', os.path.join(b.CSRC, 'gen_attn_bwd_sp.py'))
+    gen = importlib.util.module_from_spec(spec)
+    for k in ('SPX_DROP', 'SPX_OPTS'):
+        assert not os.environ.get(k), f'{k} is set: the committed stream is the default build'
+    spec.loader.exec_module(gen)
+    stream, _ = gen.generate()
+    text = gen.render(stream)
+    assert text == open(os.path.join(b.CSRC, 'attn_bwd_sp_body.inc')).read(), 'attn_bwd_sp_body.inc is stale: run python pixparse_amd/csrc/gen_attn_bwd_sp.py'
+    body = text[text.index('LOOP%=:'):text.index('DRAIN0%=:')]
+    assert body.count('v_mfma_f32_32x32x16_bf16') == 6 * 80 and body.count('s_barrier') == 6          # six unrolled passes, one rendezvous each
+    assert body.count('v_exp_f32') == 6 * 64 and body.count('ds_read_b64_tr_b16') == 6 * 64 and body.count('ds_write_b64') == 6 * 16
+    assert not re.search(r'scratch_|v_pk_mul_f32', text)
+    # the hazard pass: a VALU read of an accumulator right behind the MFMA that writes it must be refused
+    H = gen.Hazards()
+    H.emit(gen.mfma(('v', 0), ('v', 128), ('a', 128), ('v', 96), 16, 4, 4, 16))
+    with pytest.raises(RuntimeError, match='read too early'):
+        H.emit(gen.v_exp(0))
+    # ... and an LDS read is waited for, with the count of younger LDS operations, before its first consumer
+    H = gen.Hazards()
+    H.emit(gen.ds_read_b128(128, 'arow0', 0))
+    H.emit(gen.ds_read_b128(132, 'arow1', 0))
+    H.emit(gen.mfma(('v', 0), ('v', 128), ('a', 128), '0', 16, 4, 4, 16))
+    assert [i.text for i in H.out][2] == 's_waitcnt lgkmcnt(1)'
+
+
 def test_binding_loads_torch_before_the_hip_library():
     """regression: dlopen of libcruller_hip.so before torch maps a second HIP runtime (torch ships its own libamdhip64) and
     every later launch fails with "no ROCm-capable device" -- build() followed by smoke() in one process hit this"""
