@@ -170,6 +170,13 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
  *   (non-causal); 3 = single pass in its C++ form (reference of the hand-placed stream: bit-identical results). */
 size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
 int crl_attn_bwd_set_mode(int mode);
+/* Single pass only: key blocks per workgroup.  A workgroup walks `chain` consecutive 256-key blocks of its (batch, head) and adds each
+ * block's partial dQ to what the blocks before it left in the slab (read back tile by tile as the C operand of the tile's first dQ MFMA),
+ * so the reduce adds ceil(ceil(Nk / 256) / chain) slabs instead of ceil(Nk / 256).  0 (default) = chosen per problem from the simulated
+ * makespan of the workgroups on the CUs not reserved for RCCL (crl_gemm_set_reserved_cus); n >= 1 forces n (tests, A/B).  dK / dV do not
+ * depend on it; dQ carries one more bf16 rounding of the running sum per link (3.5e-3 instead of 2.6e-3 relative L2 against fp32 at
+ * chain 4, 25 key blocks).  crl_attn_bwd_ws_bytes stays sized for chain 1. */
+int crl_attn_bwd_set_chain(int chain);
 int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,

@@ -15,7 +15,9 @@
 // Tiles of 64 rows x 64 bf16 (128-B rows) are staged by bounds-checked LDS-DMA (rows past the end
 // of the sequence arrive as zeros) with one XOR swizzle that is conflict-free for BOTH the
 // ds_read_b128 row reads and the transposed reads.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "attn_frag.h"
 
@@ -753,13 +755,17 @@ constexpr int SP_DUMMY = SP_DS + 2 * 32768;
 constexpr int SP_LDS = SP_DUMMY + 256;
 
 template <bool PRE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ki = lane & 31, hh = lane >> 5;
-  int bh, kblk;
-  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, kblk);
+  // a chain of `chain` consecutive key blocks per workgroup, full chains first (see attn_bwd_spx_kernel)
+  int bh, cidx;
+  const int nfull_wg = nfull * a.B * a.H;
+  if ((int)blockIdx.x < nfull_wg) block_to_bh_tile(blockIdx.x, nfull, a.B * a.H, bh, cidx);
+  else { block_to_bh_tile(blockIdx.x - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
+  const int kb_first = cidx * chain, kb_end = min(a.nkt, kb_first + chain);
   const int b = bh / a.H, h = bh % a.H;
 
   const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
@@ -772,6 +778,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
   const LaneAddr la = make_lane_addr(lane);
   const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
 
+  for (int kblk = kb_first; kblk < kb_end; ++kblk) {
+  if (kblk != kb_first) __syncthreads();           // every wave is done with the previous key block's LDS
   const int key_wg = kblk * 256;
   const int key0 = key_wg + wave * 64;            // this wave's 64 keys
   const bool wave_live = key0 < a.Nk;
@@ -818,9 +826,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
     typedef short short8v __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
-  // partial dQ of this key block: rows q of batch b in slab kblk; bounds-checked stores drop the rows past Nq
-  const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(slabs + (int64_t)kblk * slab_stride + (int64_t)b * a.Nq * (a.H * 64), 0,
+  // running partial dQ of this chain: rows q of batch b in slab cidx; bounds-checked stores drop the rows past Nq.  The first key block
+  // of a chain starts from zero (a descriptor without records), the others from what the block before them stored.
+  const __amdgpu_buffer_rsrc_t rslab = __builtin_amdgcn_make_buffer_rsrc(slabs + (int64_t)cidx * slab_stride + (int64_t)b * a.Nq * (a.H * 64), 0,
                                                                         (int)((int64_t)a.Nq * (a.H * 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rprev = __builtin_amdgcn_make_buffer_rsrc(slabs + (int64_t)cidx * slab_stride + (int64_t)b * a.Nq * (a.H * 64), 0,
+                                                                        kblk == kb_first ? 0 : (int)((int64_t)a.Nq * (a.H * 64) * 2), 0x00020000);
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -894,7 +905,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
   auto phase_b = [&](auto slotc, int t) {
     constexpr int SLOT = decltype(slotc)::value;
     const char* dsr = smem + SP_DS + SLOT * 32768;
-    f32x16 dq = zero16();
+    const uint32_t row_off = t >= 0 ? (uint32_t)(t * 64 + 32 * qh + ki) * (uint32_t)(a.H * 64 * 2) + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2) : 0xfffffff0u;
+    f32x16 dq;                            // starts from the chain's running partial (bf16 pairs -> fp32: the C operand of the first MFMA)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(rprev, row_off + (t >= 0 ? 16 * g4 : 0), 0, 0);
+      dq[4 * g4] = __uint_as_float(w2[0] << 16); dq[4 * g4 + 1] = __uint_as_float(w2[0] & 0xffff0000u);
+      dq[4 * g4 + 2] = __uint_as_float(w2[1] << 16); dq[4 * g4 + 3] = __uint_as_float(w2[1] & 0xffff0000u);
+    }
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if (key_wg + 64 * w < a.Nk) {       // wave-uniform: tiles of waves without keys hold no dS
@@ -902,7 +921,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
         for (int kk = 0; kk < 4; ++kk) dq = mfma32(ka[4 * w + kk], tr_read(dsr + w * 8192, trs0, trs1, 16 * kk), dq);
       }
     }
-    const uint32_t row_off = t >= 0 ? (uint32_t)(t * 64 + 32 * qh + ki) * (uint32_t)(a.H * 64 * 2) + (uint32_t)((h * 64 + 32 * dbq + 4 * hh) * 2) : 0xfffffff0u;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -944,6 +962,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
         }
     }
   }
+  }   // key blocks of the chain
 }
 
 // The same algorithm as ONE hand-placed instruction stream (gen_attn_bwd_sp.py -> attn_bwd_sp_body.inc; register map, schedule and the
@@ -952,20 +971,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
 // (base-2 logits straight from the MFMAs: no multiply per element).
 constexpr int SPX_SLOT = 16384 + 1024;
 constexpr int SPX_DS = 65536;
-constexpr int SPX_LDS = SPX_DS + 2 * 32768;
+constexpr int SPX_PART = SPX_DS + 2 * 32768;       // running partial dQ tiles: ring of 3 buffers x 4 waves x 2 KiB
+constexpr int SPX_LDS = SPX_PART + 3 * 8192;
 
 #ifdef SPX_STAMPS
 __device__ unsigned long long spx_dbg[2 * 4096];    // diagnostic build: (shader cycles, 100 MHz ticks) of the asm statement per workgroup
 constexpr int SPX_TR_WG = 64, SPX_TR_PASSES = 128;  // per-pass trace of the first 64 workgroups: [stamp k][workgroup][pass]; the others share a dump slot
 __device__ unsigned long long spx_trace[6 * (SPX_TR_WG + 1) * SPX_TR_PASSES];
 #endif
-__global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride) {
+// One workgroup = a CHAIN of `chain` consecutive 256-key blocks of one (batch, head), walked one after the other: the partial dQ of a key
+// block is added to what the blocks before it in the chain left in the slab (read back tile by tile through LDS-DMA, as the C operand of
+// the tile's first dQ MFMA), so a chain leaves ONE slab and attn_dq_reduce_kernel adds ceil(nkt / chain) of them instead of nkt.
+__global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ki = lane & 31, hh = lane >> 5;
-  int bh, kblk;
-  block_to_bh_tile(blockIdx.x, a.nkt, a.B * a.H, bh, kblk);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // longest first: the nfull = nkt / chain full chains of every (batch, head), then the remainders (workgroups start in index order, so
+  // the short ones fill the last round)
+  int bh, cidx;
+  const int nfull_wg = nfull * a.B * a.H;
+  if ((int)blockIdx.x < nfull_wg) block_to_bh_tile(blockIdx.x, nfull, a.B * a.H, bh, cidx);
+  else { block_to_bh_tile(blockIdx.x - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
   const int b = bh / a.H, h = bh % a.H;
   const int HD2 = a.H * 64 * 2;                    // bytes per slab row
 
@@ -975,72 +1000,92 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
   const u32x4 rdk = make_srd(a.dk + b * a.dk_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dk_rs + 64) * 2));
   const u32x4 rdv = make_srd(a.dv + b * a.dv_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dv_rs + 64) * 2));
-  const u32x4 rslab = make_srd(slabs + (int64_t)kblk * slab_stride + (int64_t)b * a.Nq * (a.H * 64), (uint32_t)((int64_t)a.Nq * HD2));
+  const u16* slab = slabs + (int64_t)cidx * slab_stride + (int64_t)b * a.Nq * (a.H * 64);
+  const u32x4 rslab = make_srd(slab, (uint32_t)((int64_t)a.Nq * HD2));
   const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
   // row constants: wave 1 fetches -delta, the others -lse/scale (waves 2 / 3 into spare vectors of the slot: every wave issues the same five pieces)
   const float* rcp = wave == 1 ? a.delta + ((int64_t)b * a.H + h) * a.Nq : a.delta + nrows + ((int64_t)b * a.H + h) * a.Nq;
   const u32x4 rrc = make_srd(rcp, (uint32_t)a.Nq * 4u);
   const uint32_t sbase = lds_addr_of(smem);
-  const LaneAddr la = make_lane_addr(lane);
-  const int key_wg = kblk * 256, key0 = key_wg + wave * 64;
   const int qh = wave >> 1, dbq = wave & 1;        // dQ phase: this wave's block = d rows 32 dbq.., q columns 32 qh..
-
-  uint32_t arow0 = sbase + la.row[0], arow1 = sbase + la.row[1], arow2 = sbase + la.row[2], arow3 = sbase + la.row[3];
-  uint32_t atr0 = sbase + la.tr[0][0], atr1 = sbase + la.tr[0][1], atr2 = sbase + la.tr[1][0], atr3 = sbase + la.tr[1][1];
-  uint32_t aseed = sbase + 16384 + 16 * hh;
-  const uint32_t dsw = sbase + SPX_DS + wave * 8192 + ki * 128 + 8 * hh;
-  const int sw = swz64(ki);
-  uint32_t adsw0 = dsw + ((0 ^ sw) << 4), adsw1 = dsw + ((1 ^ sw) << 4), adsw2 = dsw + ((2 ^ sw) << 4), adsw3 = dsw + ((3 ^ sw) << 4),
-           adsw4 = dsw + ((4 ^ sw) << 4), adsw5 = dsw + ((5 ^ sw) << 4), adsw6 = dsw + ((6 ^ sw) << 4), adsw7 = dsw + ((7 ^ sw) << 4);
-  uint32_t atrs0 = sbase + SPX_DS + (qh ? la.tr[1][0] : la.tr[0][0]), atrs1 = sbase + SPX_DS + (qh ? la.tr[1][1] : la.tr[0][1]);
-  uint32_t atrk0 = sbase + SPX_DS + (dbq ? la.tr[1][0] : la.tr[0][0]), atrk1 = sbase + SPX_DS + (dbq ? la.tr[1][1] : la.tr[0][1]);
-  const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
-  uint32_t sqv = sq.v, sdov = sdo.v, rcv = (uint32_t)lane * 4u;
-  uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 8 * hh) * 2);   // 16 bytes per lane (the stream swaps lane halves)
-  uint32_t dkv = (uint32_t)(((int64_t)(key0 + ki) * a.dk_rs + 8 * hh) * 2), dvv = (uint32_t)(((int64_t)(key0 + ki) * a.dv_rs + 8 * hh) * 2);   // 16 bytes per lane
-  const int kr0 = min(key0 + ki, a.Nk - 1), kr1 = min(key0 + 32 + ki, a.Nk - 1);
-  uint32_t koff0 = (uint32_t)(((int64_t)kr0 * a.k_rs + 8 * hh) * 2), koff1 = (uint32_t)(((int64_t)kr1 * a.k_rs + 8 * hh) * 2);
-  uint32_t voff0 = (uint32_t)(((int64_t)kr0 * a.v_rs + 8 * hh) * 2), voff1 = (uint32_t)(((int64_t)kr1 * a.v_rs + 8 * hh) * 2);
-
   const int nqt64 = (a.Nq + 63) / 64;
   const uint32_t s_qstep = (uint32_t)(64 * a.q_rs * 2), s_dostep = (uint32_t)(64 * a.do_rs * 2);
   const uint32_t s_q32 = (uint32_t)(32 * a.q_rs * 2), s_do32 = (uint32_t)(32 * a.do_rs * 2);
-  const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
+  const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_slab3 = 3u * s_slabstep, s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
   const float s_dkscale = a.scale;
   const uint32_t s_iters = (uint32_t)nqt64;        // + the drain behind the loop: dV / dK of the last block, dQ of the last tile
-  // running state: the DMA of pass t fetches tile t + 2; the slab offset advances before the stores of a pass (tile t - 1)
-  uint32_t s_qoff = 2u * s_qstep, s_dooff = 2u * s_dostep, s_rcoff = 2u * 256u, s_slaboff = (uint32_t)(-2 * (int)s_slabstep);
   const uint32_t s_m0q = sbase + wave * 1024, s_m0rc = sbase + 16384 + wave * 256;     // + ring slot + piece: immediates of the unrolled passes
-  uint32_t s_tmp1, s_cnt;
+  const uint32_t s_m0p = sbase + SPX_PART + wave * 2048;                                // + partial buffer + piece
+  const uint32_t s_krs2 = (uint32_t)(a.k_rs * 2), s_vrs2 = (uint32_t)(a.v_rs * 2), s_dkrs2 = (uint32_t)(a.dk_rs * 2), s_dvrs2 = (uint32_t)(a.dv_rs * 2);
 
-  // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: whatever dS the clamped fragments of such keys produce, it meets a
-  // zero K^T row in dQ), query tiles 0 and 1 -> ring slots 0 and 1
+  const int kb_end = min(a.nkt, (cidx + 1) * chain);
+  for (int kblk = cidx * chain; kblk < kb_end; ++kblk) {
+    // the first key block of a chain starts from zero: a descriptor without records returns zeros
+    const u32x4 rprev = make_srd(slab, kblk == cidx * chain ? 0u : (uint32_t)((int64_t)a.Nq * HD2));
+    // every per-lane value is derived afresh from an OPAQUE copy of the thread index: hoisted out of the key-block loop it would have to
+    // live across the stream, which leaves the compiler 32 vector registers (26 of them its operands) -- i.e. in scratch memory
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, ki = tid & 31, hh = (tid >> 5) & 1;
+    const LaneAddr la = make_lane_addr(lane);
+    const int key_wg = kblk * 256, key0 = key_wg + wave * 64;
+    uint32_t arow0 = sbase + la.row[0], arow1 = sbase + la.row[1], arow2 = sbase + la.row[2], arow3 = sbase + la.row[3];
+    uint32_t atr0 = sbase + la.tr[0][0], atr1 = sbase + la.tr[0][1], atr2 = sbase + la.tr[1][0], atr3 = sbase + la.tr[1][1];
+    uint32_t aseed = sbase + 16384 + 16 * hh;
+    const uint32_t dsw = sbase + SPX_DS + wave * 8192 + ki * 128 + 8 * hh;
+    const int sw = swz64(ki);
+    uint32_t adsw0 = dsw + ((0 ^ sw) << 4), adsw1 = dsw + ((1 ^ sw) << 4), adsw2 = dsw + ((2 ^ sw) << 4), adsw3 = dsw + ((3 ^ sw) << 4),
+             adsw4 = dsw + ((4 ^ sw) << 4), adsw5 = dsw + ((5 ^ sw) << 4), adsw6 = dsw + ((6 ^ sw) << 4), adsw7 = dsw + ((7 ^ sw) << 4);
+    uint32_t atrs0 = sbase + SPX_DS + (qh ? la.tr[1][0] : la.tr[0][0]), atrs1 = sbase + SPX_DS + (qh ? la.tr[1][1] : la.tr[0][1]);
+    uint32_t atrk0 = sbase + SPX_DS + (dbq ? la.tr[1][0] : la.tr[0][0]), atrk1 = sbase + SPX_DS + (dbq ? la.tr[1][1] : la.tr[0][1]);
+    const StageOff sq = make_stage_off(tid, a.q_rs), sdo = make_stage_off(tid, a.do_rs), sk = make_stage_off(tid, a.k_rs);
+    uint32_t sqv = sq.v, sdov = sdo.v, rcv = (uint32_t)lane * 4u;
+    uint32_t slabv = (uint32_t)(32 * qh + ki) * (uint32_t)HD2 + (uint32_t)((h * 64 + 32 * dbq + 8 * hh) * 2);   // 16 bytes per lane (the stream swaps lane halves)
+    // read-back address of the running partial (undoes the lane-half exchange of the store: gen_attn_bwd_sp.py load_part)
+    uint32_t apart = sbase + SPX_PART + wave * 2048 + ki * 16 + 8 * hh;
+    // (the K / V fragment and dK / dV store offsets -- row key0 + ki, clamped to Nk - 1 for the loads, 16 bytes at channel 8 hh -- are
+    // computed inside the stream from rcv and these scalars)
+    const uint32_t s_key0 = (uint32_t)key0, s_nkm1 = (uint32_t)(a.Nk - 1);
+    // running state: the DMA of pass t fetches tile t + 2; the slab offset advances before the stores of a pass (tile t - 1)
+    uint32_t s_qoff = 2u * s_qstep, s_dooff = 2u * s_dostep, s_rcoff = 2u * 256u, s_slaboff = (uint32_t)(-2 * (int)s_slabstep);
+    uint32_t s_tmp1, s_cnt;
+
+    // every wave has left the previous key block's stream (its last LDS reads are behind a full wait): the LDS is free
+    if (kblk != cidx * chain) __syncthreads();
+    // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: whatever dS the clamped fragments of such keys produce, it meets a
+    // zero K^T row in dQ), query tiles 0 and 1 -> ring slots 0 and 1, the running partials of tiles 0 and 1 -> partial buffers 0 and 1
 #pragma unroll
-  for (int j = 0; j < 4; ++j) stage64(rk, sbase + SPX_DS + j * 8192, sk, key_wg + 64 * j, a.k_rs, wave);
+    for (int j = 0; j < 4; ++j) stage64(rk, sbase + SPX_DS + j * 8192, sk, key_wg + 64 * j, a.k_rs, wave);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const uint32_t base = sbase + t * SPX_SLOT;
-    stage64(rq, base, sq, t * 64, a.q_rs, wave);
-    stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
-    dma4(rrc, base + 16384 + wave * 256, rcv, (uint32_t)t * 256u);
-  }
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t base = sbase + t * SPX_SLOT;
+      stage64(rq, base, sq, t * 64, a.q_rs, wave);
+      stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
+      dma4(rrc, base + 16384 + wave * 256, rcv, (uint32_t)t * 256u);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      dma16(rprev, s_m0p + t * 8192u, slabv, (uint32_t)t * s_slabstep);
+      dma16(rprev, s_m0p + t * 8192u + 1024u, slabv, (uint32_t)t * s_slabstep + 32u);
+    }
 #ifdef SPX_STAMPS
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  uint32_t s_dbgoff = 0;
-  unsigned long long st0, st1, st2, st3, st4, st5;
-  const int trw = wave == 0 && blockIdx.x < SPX_TR_WG && nqt64 + 1 < SPX_TR_PASSES ? (int)blockIdx.x : SPX_TR_WG;
-  unsigned long long* const dbg0 = spx_trace + (0 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
-  unsigned long long* const dbg1 = spx_trace + (1 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
-  unsigned long long* const dbg2 = spx_trace + (2 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
-  unsigned long long* const dbg3 = spx_trace + (3 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
-  unsigned long long* const dbg4 = spx_trace + (4 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
-  unsigned long long* const dbg5 = spx_trace + (5 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t s_dbgoff = 0;
+    unsigned long long st0, st1, st2, st3, st4, st5;
+    const int trw = wave == 0 && blockIdx.x < SPX_TR_WG && nqt64 + 1 < SPX_TR_PASSES ? (int)blockIdx.x : SPX_TR_WG;
+    unsigned long long* const dbg0 = spx_trace + (0 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    unsigned long long* const dbg1 = spx_trace + (1 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    unsigned long long* const dbg2 = spx_trace + (2 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    unsigned long long* const dbg3 = spx_trace + (3 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    unsigned long long* const dbg4 = spx_trace + (4 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
+    unsigned long long* const dbg5 = spx_trace + (5 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
 #endif
 #include "attn_bwd_sp_body.inc"
 #ifdef SPX_STAMPS
-  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  if (tid == 0 && blockIdx.x < 4096) { spx_dbg[2 * blockIdx.x] = c1 - c0; spx_dbg[2 * blockIdx.x + 1] = r1 - r0; }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { spx_dbg[2 * blockIdx.x] = c1 - c0; spx_dbg[2 * blockIdx.x + 1] = r1 - r0; }
 #endif
+  }
 }
 
 // dq[b, q, h*64 + d] = bf16(scale * sum over slabs (fp32, in slab order) of slab[s][b][q][h*64 + d]); 16 bytes per thread and slab
@@ -1157,6 +1202,50 @@ extern "C" int crl_attn_bwd_set_mode(int mode) {
 // auto: the single pass pays from about sixteen query tiles per workgroup on (its prologue / epilogue -- K^T fragments, 128 accumulators
 // in and out -- cost as much as ~5 tile passes): the ViT encoders (N = 2401 ... 24 935) and the decoder's cross-attention at cfg-3
 // (Nq = 1023: 0.63 against 0.67 ms per layer), not short target sequences
+static int g_bwd_chain = 0;     // key blocks per workgroup of the hand-placed single pass: 0 = auto
+extern "C" int crl_attn_bwd_set_chain(int chain) {
+  if (chain < 0) { crl_set_error("crl_attn_bwd_set_chain: 0 auto, n >= 1 key blocks per workgroup"); return -1; }
+  g_bwd_chain = chain;
+  return 0;
+}
+int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_gemm_set_reserved_cus)
+// Key blocks per workgroup.  A chain of c blocks leaves one slab instead of c (the reduce reads ceil(nkt / c) slabs: ~0.1 of a key block's
+// time each, both proportional to Nq) but its workgroups are c times longer (fewer of them to balance over the CUs) and fewer workgroups
+// of a head run side by side (the query tiles they share come from L2 only while they do: ~0.06 of a block per extra link measured; priced at 0.1, as each link also adds a bf16 rounding of the running sum).
+// The workgroups start longest first -- nfull = nkt / c full chains per head, then the remainders --; the makespan of that order on the
+// available CUs is simulated once per (nkt, heads, CUs) and the cheapest c kept.  Same-box A/B at cfg-3 (25 key blocks, 128 heads):
+// c = 3 / 4 / 6 within noise of each other, -2.5 ms per step against c = 1, c = 12 half of that (profiles/r4_attn_chain.txt).
+static int bwd_chain_length(int nkt, int BH, bool stream) {
+  if (g_bwd_chain > 0) return g_bwd_chain < nkt ? g_bwd_chain : nkt;      // forced: both forms (same arithmetic at the same chain length)
+  if (!stream) return 1;
+  static int memo_nkt = 0, memo_bh = 0, memo_cu = 0, memo_c = 1;
+  const int ncu = crl_gemm_cus();
+  if (nkt == memo_nkt && BH == memo_bh && ncu == memo_cu) return memo_c;
+  double best = 1e30;
+  int best_c = 1;
+  std::vector<int> busy((size_t)ncu);
+  for (int c = 1; c <= nkt; ++c) {
+    const int nfull = nkt / c, rem = nkt % c;
+    // workgroups start in index order on the CU that frees up first (a min-heap over the CUs' finish times)
+    std::fill(busy.begin(), busy.end(), 0);
+    auto later = [](int x, int y) { return x > y; };
+    int makespan = 0;
+    auto place = [&](int n, int len) {
+      for (int i = 0; i < n && len > 0; ++i) {
+        std::pop_heap(busy.begin(), busy.end(), later);
+        busy.back() += len;
+        makespan = busy.back() > makespan ? busy.back() : makespan;
+        std::push_heap(busy.begin(), busy.end(), later);
+      }
+    };
+    place(nfull * BH, c);
+    place(BH, rem);
+    const double cost = makespan + 0.1 * (nfull + (rem ? 1 : 0)) + 0.1 * (c - 1);
+    if (cost < best - 1e-9) { best = cost; best_c = c; }
+  }
+  memo_nkt = nkt; memo_bh = BH; memo_cu = ncu; memo_c = best_c;
+  return best_c;
+}
 static bool bwd_fused_wanted(int Nq, int Nk, int causal) {
   if (causal || g_bwd_parts != 7) return false;
   return g_bwd_mode >= 2 || (g_bwd_mode == 0 && Nq >= 1000 && Nk >= 1024);
@@ -1236,13 +1325,15 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
     a.nkt = (Nk + 255) / 256;
-    const int nslab = a.nkt;
+    const int chain = bwd_chain_length(a.nkt, B * H, q_prescaled && g_bwd_mode != 3);
+    const int nfull = a.nkt / chain, nchain = (a.nkt + chain - 1) / chain;
+    const int nslab = nchain;
     const int64_t slab_stride = (int64_t)B * Nq * H * 64;
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
-    if (q_prescaled && g_bwd_mode != 3) attn_bwd_spx_kernel<<<(unsigned)a.nkt * B * H, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride);
-    else if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
-    else attn_bwd_sp_kernel<false><<<(unsigned)a.nkt * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride);
+    if (q_prescaled && g_bwd_mode != 3) attn_bwd_spx_kernel<<<(unsigned)nchain * B * H, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
+    else if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
+    else attn_bwd_sp_kernel<false><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
     CRL_PROF_STOP(CRL_K_ATTN_BWD_FUSED, stream);
     CRL_LAUNCH_CHECK("crl_attn_bwd(fused)");
     const int64_t n8 = (int64_t)B * Nq * (H * 64 / 8);

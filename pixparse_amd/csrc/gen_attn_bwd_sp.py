@@ -50,7 +50,9 @@ N_HAND = 224
 SLOT = 16384 + 1024            # ring slot: Q tile | dO tile | 4 x 256 B row-constant vectors (waves 0 / 1: -lse', -delta; 2 / 3: unused copies)
 RING = 3
 DS_BASE = 65536                # two dS buffers of 32 KiB: 65536, 98304 (toggle = xor 0x8000); K is staged through the first one
-LDS_BYTES = DS_BASE + 2 * 32768
+PART_BASE = DS_BASE + 2 * 32768   # running partial dQ tiles of the chain: ring of three buffers (tile mod 3) x 4 waves x 2 pieces of 1 KiB
+PBUF = 8192
+LDS_BYTES = PART_BASE + 3 * PBUF
 
 
 def vr(b, n=1):
@@ -157,9 +159,11 @@ def m2_block(kb):
 
 
 def dq_quarter(w):
+    """a quarter (64 keys) of dQ^T of the previous tile; the chain starts from the running partial of the key blocks before this one
+    (load_part / unpack_part: zeros for the first key block of a chain)"""
     out = []
     for kk in range(4):
-        c = '0' if (w == 0 and kk == 0) else ('v', V_DQ)
+        c = ('v', V_DQ)
         out.append(mfma(('v', V_DQ), ('a', A_KA + 4 * (4 * w + kk)), ('v', V_DSF + 4 * kk), c, 16, 4, 4, 16))
     return out
 
@@ -213,6 +217,31 @@ def load_dsf(w, par=0):
     return out
 
 
+def load_part(par):
+    """the running partial of the tile whose dQ the NEXT pass accumulates, as the previous key block of the chain stored it (dq_store: 16
+    bytes per lane AFTER the lane-half exchange), DMA'd into partial buffer `par` (tile mod 3) two passes ago.  Read back through addresses that undo the
+    exchange: lanes 0..31 take their own first 8 bytes and those of lane + 32, lanes 32..63 the second 8 bytes of lane - 32 and their
+    own (512 bytes apart: one ds_read2st64_b64 per piece)"""
+    out = []
+    for gp in range(2):
+        dst = V_DQ + 8 * gp + 4
+        o = 16 * par + 2 * gp
+        out.append(I(f'ds_read2st64_b64 {vr(dst, 4)}, {op("apart")} offset0:{o} offset1:{o + 1}', 'ds', reads=['apart'], writes=regs('v', dst, 4)))
+    return out
+
+
+def unpack_part():
+    """bf16 pairs -> the fp32 C operand of the first dQ MFMA, in place (sources v[b+4 : b+7] are consumed in order)"""
+    out = []
+    for gp in range(2):
+        b = V_DQ + 8 * gp
+        for j in range(4):
+            src = b + 4 + j
+            out.append(valu(f'v_lshlrev_b32 v{b + 2 * j}, 16, v{src}', [f'v{src}'], [f'v{b + 2 * j}']))
+            out.append(valu(f'v_and_b32 v{b + 2 * j + 1}, 0xffff0000, v{src}', [f'v{src}'], [f'v{b + 2 * j + 1}']))
+    return out
+
+
 def dq_store():
     """dQ^T block -> bf16 in place -> slab (rows past Nq, and the whole tile -1, fall off the descriptor).  Pairs of 4-channel groups
     are exchanged between the lane halves (v_permlane32_swap, guide T21) so that every lane owns 16 contiguous bytes: two 16-byte
@@ -249,6 +278,19 @@ def dma_tile(ring):
     return out
 
 
+def dma_part(ring):
+    """the running partial of tile t + 2 (this pass stores tile t - 1: three slab steps ahead of the store offset) into partial buffer
+    `ring`: the two 16-byte pieces per lane exactly as dq_store wrote them.  rprev has zero records for the first key block of a chain
+    (zeros arrive).  These loads come from HBM (a workgroup reads back what it wrote a whole key block earlier): they are the YOUNGEST
+    memory operations of a pass, so that the rendezvous of the next pass (vmcnt(4): two slab stores + these two) does not wait for them --
+    the pass after that does."""
+    out = [salu(f's_add_u32 {op("s_tmp1")}, {op("s_slaboff")}, {op("s_slab3")}'), salu(f's_add_u32 m0, {op("s_m0p")}, {ring * PBUF}'),
+           I(f's_nop 0\n\tbuffer_load_dwordx4 {op("slabv")}, {op("rprev")}, {op("s_tmp1")} offen lds', 'vmem', reads=['slabv'], cost=12),
+           salu(f's_add_u32 {op("s_tmp1")}, {op("s_tmp1")}, 32'), salu(f's_add_u32 m0, {op("s_m0p")}, {ring * PBUF + 1024}'),
+           I(f's_nop 0\n\tbuffer_load_dwordx4 {op("slabv")}, {op("rprev")}, {op("s_tmp1")} offen lds', 'vmem', reads=['slabv'], cost=12)]
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- placement
 class Gaps:
     def __init__(self, n):
@@ -265,6 +307,20 @@ class Gaps:
         width = hi - lo + 1
         for j, ins in enumerate(inss):
             self.g[lo + (j * width) // n].append(ins)
+
+    def fill(self, lo, hi, inss):
+        """instructions in order into gaps lo..hi, cheapest gaps first: the lowest level L such that topping every gap up to L (left to
+        right, order kept) takes them all"""
+        for level in range(0, 400, 4):
+            room = [max(0, (level - self.cost(g)) // 4) for g in range(lo, hi + 1)]
+            if sum(room) >= len(inss):
+                k = 0
+                for g, r in zip(range(lo, hi + 1), room):
+                    for _ in range(r):
+                        if k < len(inss):
+                            self.g[g].append(inss[k]); k += 1
+                return
+        raise RuntimeError('fill: no room')
 
     def cost(self, gap):
         return sum(i.cost for i in self.g[gap])
@@ -316,12 +372,19 @@ def build_iteration(p):
     # ---- slot 1: LDS-DMA of tile t + 2
     g0 = 20
     G.spread(g0 + 7, g0 + 16, dma_tile((p + 2) % 3))
+    # ---- slot 0: the running partial of tile t - 1 -> C operand of its first dQ MFMA (MFMA 16 of the pass)
+    # (its two LDS reads were issued in the last gap of the previous pass -- see below -- and are covered by the rendezvous)
+    G.fill(0, 15, unpack_part())
     # ---- slot 3: dQ conversion + stores (dQ MFMAs are 8..11 of the slot), address toggles, ring advance of the transposed addresses
     g0 = 60
     cv, st = dq_store()
     G.spread(g0 + 14, g0 + 18, cv)
     for k in range(2):
         G.put(g0 + 19, st[k])
+    # the running partial of tile t (DMA'd one pass ago, landed at this pass's rendezvous) for the NEXT pass, into the upper halves of the
+    # accumulator block, which the conversions above have just released
+    for ins in load_part(ring_t) + dma_part((p + 2) % 3):
+        G.put(g0 + 19, ins)
     return bb, G
 
 
@@ -444,9 +507,10 @@ class Hazards:
 
 # ----------------------------------------------------------------------------------------------- whole statement
 VOPS = ['arow0', 'arow1', 'arow2', 'arow3', 'atr0', 'atr1', 'atr2', 'atr3', 'aseed'] + [f'adsw{i}' for i in range(8)] + \
-       ['atrs0', 'atrs1', 'sqv', 'sdov', 'rcv', 'slabv', 'dkv', 'dvv', 'atrk0', 'atrk1', 'koff0', 'koff1', 'voff0', 'voff1']
-SRDS = ['rq', 'rdo', 'rrc', 'rk', 'rv', 'rdk', 'rdv', 'rslab']
-SIN = ['s_qstep', 's_dostep', 's_q32', 's_do32', 's_slabstep', 's_dk32', 's_dv32', 's_dkscale', 's_iters', 's_m0q', 's_m0rc']
+       ['atrs0', 'atrs1', 'sqv', 'sdov', 'rcv', 'slabv', 'atrk0', 'atrk1', 'apart']
+SRDS = ['rq', 'rdo', 'rrc', 'rk', 'rv', 'rdk', 'rdv', 'rslab', 'rprev']
+SIN = ['s_qstep', 's_dostep', 's_q32', 's_do32', 's_slabstep', 's_dk32', 's_dv32', 's_dkscale', 's_iters', 's_m0q', 's_m0rc', 's_slab3', 's_m0p',
+       's_key0', 's_nkm1', 's_krs2', 's_vrs2', 's_dkrs2', 's_dvrs2']
 SRW = ['s_qoff', 's_dooff', 's_rcoff', 's_slaboff']
 STMP = ['s_tmp1', 's_cnt']
 
@@ -459,10 +523,18 @@ def generate():
         H.out.append(I('s_memtime %[st2]', 'salu'))
     # K / V row fragments of this wave's 64 keys straight into the accumulator file (rows past Nk are clamped to the last key): issued FIRST,
     # their latency and that of the staging DMA runs under the ~200 register initialisations below
+    # (per-lane offsets from the lane id in rcv = 4 lane: key row ki = lane & 31 (+ 32 kb), clamped to the last key; 16 bytes hh = lane >> 5.
+    # Computed here, in registers the stream does not use yet, instead of being handed in: the compiler has 32 vector registers for ALL operands)
+    for t in [f'v_lshrrev_b32 v0, 2, {op("rcv")}', 'v_and_b32 v0, 31, v0', f'v_lshrrev_b32 v1, 7, {op("rcv")}', 'v_lshlrev_b32 v1, 4, v1',
+              f'v_add_u32 v2, {op("s_key0")}, v0', 'v_add_u32 v3, 32, v2', f'v_min_u32 v2, {op("s_nkm1")}, v2', f'v_min_u32 v3, {op("s_nkm1")}, v3',
+              f'v_mul_lo_u32 v6, v2, {op("s_krs2")}', f'v_mul_lo_u32 v7, v3, {op("s_krs2")}',
+              f'v_mul_lo_u32 v8, v2, {op("s_vrs2")}', f'v_mul_lo_u32 v9, v3, {op("s_vrs2")}',
+              'v_add_u32 v6, v6, v1', 'v_add_u32 v7, v7, v1', 'v_add_u32 v8, v8, v1', 'v_add_u32 v9, v9, v1']:
+        H.out.append(I(t, 'valu'))
     for kb in range(2):
         for ks in range(4):
-            E(I(f'buffer_load_dwordx4 {ar(A_KF + 4 * (4 * kb + ks), 4)}, {op(f"koff{kb}")}, {op("rk")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'koff{kb}']))
-            E(I(f'buffer_load_dwordx4 {ar(A_VF + 4 * (4 * kb + ks), 4)}, {op(f"voff{kb}")}, {op("rv")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'voff{kb}']))
+            E(I(f'buffer_load_dwordx4 {ar(A_KF + 4 * (4 * kb + ks), 4)}, v{6 + kb}, {op("rk")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'v{6 + kb}']))
+            E(I(f'buffer_load_dwordx4 {ar(A_VF + 4 * (4 * kb + ks), 4)}, v{8 + kb}, {op("rv")}, 0 offen offset:{32 * ks}', 'vmem', reads=[f'v{8 + kb}']))
     for i in range(128):
         E(valu(f'v_accvgpr_write_b32 a{i}, 0', [], [f'a{i}']))
     for b in (V_P[0], V_P[1]):
@@ -481,7 +553,7 @@ def generate():
         off = (kk >> 2) * 8192 + (kk & 3) * 2048
         E(ds_read_tr('a', A_KA + 4 * kk, 'atrk0', off))
         E(ds_read_tr('a', A_KA + 4 * kk + 2, 'atrk1', off))
-    for ins in load_seeds(0) + load_qf(0):
+    for ins in load_seeds(0) + load_qf(0) + load_part(2):     # pass 0 accumulates dQ of "tile -1" (dS = 0, stored nowhere): any seed will do
         E(ins)
     H.drain('s_waitcnt lgkmcnt(0)')
     if STAMPS:
@@ -508,7 +580,7 @@ def generate():
         # every LDS read of the previous pass are complete.  It sits BEHIND the first BARRIER_AT MFMAs of the pass (S / dP of the next block from
         # operands already in registers; their gaps hold VALU work only), so the wait overlaps matrix work instead of draining the pipe.
         def rendezvous():
-            H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
+            H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
             if STAMPS:
                 # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
                 H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
@@ -539,7 +611,7 @@ def generate():
     # spend on a tile of zero rows.  The pass that follows pass p reads the dS buffer of parity p & 1: one copy per parity.
     for par in range(2):
         H.out.append(I(f'DRAIN{par}%=:', 'label'))
-        H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)')
+        H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
         E(I('s_barrier', 'barrier'))
         E(salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
         H.settle_mfma()                       # the S / dP results of the last pass are not read any more
@@ -547,6 +619,8 @@ def generate():
             E(ins)
         for m in m2_block(1):
             E(m)
+        for ins in unpack_part():
+            E(ins)
         for w in range(4):                    # one quarter of dS^T at a time (the fragment registers are shared); once per workgroup
             if w:
                 for ins in load_dsf(w, par):
@@ -568,8 +642,13 @@ def generate():
         H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) + '\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)', 'salu'))
     E(I('s_nop 7\n\ts_nop 7', 'nop'))
     H.settle_mfma()
+    # per-lane store offsets (16 bytes per lane): row key0 + ki of dK / dV, channel 8 hh; rows past Nk fall off the descriptors
+    for t in [f'v_lshrrev_b32 v216, 2, {op("rcv")}', 'v_and_b32 v216, 31, v216', f'v_lshrrev_b32 v218, 7, {op("rcv")}', 'v_lshlrev_b32 v218, 4, v218',
+              f'v_add_u32 v216, {op("s_key0")}, v216', f'v_mul_lo_u32 v217, v216, {op("s_dvrs2")}', f'v_mul_lo_u32 v216, v216, {op("s_dkrs2")}',
+              'v_add_u32 v216, v216, v218', 'v_add_u32 v217, v217, v218']:
+        H.out.append(I(t, 'valu'))
     tmp = 0
-    for which, abase, voff, srd, s32 in (('dk', A_DK, 'dkv', 'rdk', 's_dk32'), ('dv', A_DV, 'dvv', 'rdv', 's_dv32')):
+    for which, abase, voff, srd, s32 in (('dk', A_DK, 'v216', 'rdk', 's_dk32'), ('dv', A_DV, 'v217', 'rdv', 's_dv32')):
         for kb in range(2):
             for db in range(2):
                 acc = abase + 16 * (2 * kb + db)
@@ -588,7 +667,7 @@ def generate():
                     E(valu(f'v_permlane32_swap_b32 v{r}, v{r + 2}', [f'v{r}', f'v{r + 2}'], [f'v{r}', f'v{r + 2}'], kind='perm'))
                     E(valu(f'v_permlane32_swap_b32 v{r + 1}, v{r + 3}', [f'v{r + 1}', f'v{r + 3}'], [f'v{r + 1}', f'v{r + 3}'], kind='perm'))
                     soff = op(s32) if kb else '0'
-                    E(I(f'buffer_store_dwordx4 {vr(r, 4)}, {op(voff)}, {op(srd)}, {soff} offen offset:{64 * db + 16 * g}\n\ts_nop 1', 'vmem', reads=regs('v', r, 4)))
+                    E(I(f'buffer_store_dwordx4 {vr(r, 4)}, {voff}, {op(srd)}, {soff} offen offset:{64 * db + 16 * g}\n\ts_nop 1', 'vmem', reads=regs('v', r, 4)))
     return H.out, G
 
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
     'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),
+    'crl_attn_bwd_set_chain': (I, [I]),
     'crl_debug_occupy_cus': (I, [I, ctypes.c_double, P, P]),
     'crl_prof_begin': (I, [I]),
     'crl_prof_end': (I, [I, P, P, P]),
@@ -111,7 +112,7 @@ def load(path: str = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('PIXPARSE_AMD_LIB') or LIB_PATH      # PIXPARSE_AMD_LIB: same-box A/B against another build of the library
     if not os.path.exists(path):
         raise HipLibraryError(
             f'{path} not found: build it with `python -m pixparse_amd.build` (hipcc --offload-arch=gfx950). '
@@ -123,6 +124,8 @@ def load(path: str = None) -> ctypes.CDLL:
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if os.environ.get('PIXPARSE_AMD_LIB') == path:
+                continue                        # an older build under A/B may lack newer entry points: using one raises AttributeError
             raise HipLibraryError(f'{path} does not export {name}') from e
         fn.restype = res
         fn.argtypes = args

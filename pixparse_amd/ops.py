@@ -250,6 +250,8 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, 
         _attn_mode_env_applied = True
         if os.environ.get('PIXPARSE_AMD_ATTN_BWD_MODE'):
             hip.call('crl_attn_bwd_set_mode', int(os.environ['PIXPARSE_AMD_ATTN_BWD_MODE']))
+        if os.environ.get('PIXPARSE_AMD_ATTN_BWD_CHAIN'):   # key blocks per workgroup of the single pass (crl_attn_bwd_set_chain; 0 = auto)
+            hip.call('crl_attn_bwd_set_chain', int(os.environ['PIXPARSE_AMD_ATTN_BWD_CHAIN']))
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o, d_o, dq, dk, dv)

@@ -136,9 +136,10 @@ def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk, pre):
     ops.attn_fwd(q, k, v, o, lse, H, scale, False, q_prescaled=pre)
     delta = torch.empty(2, B, H, Nq, device=dev)
 
-    def bwd(mode):
+    def bwd(mode, chain=0):
         dq, dk, dv = (torch.full((B, n, D), float('nan'), dtype=BF16, device=dev) for n in (Nq, Nk, Nk))
         hip.call('crl_attn_bwd_set_mode', mode)
+        hip.call('crl_attn_bwd_set_chain', chain)
         try:
             auto = Nq >= 1000 and Nk >= 1024
             assert (hip.query('crl_attn_bwd_ws_bytes', B, H, Nq, Nk, 0) > 0) == (mode >= 2 or (mode == 0 and auto))
@@ -146,6 +147,7 @@ def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk, pre):
             ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False, q_prescaled=pre)
         finally:
             hip.call('crl_attn_bwd_set_mode', 0)
+            hip.call('crl_attn_bwd_set_chain', 0)
         return dq, dk, dv
     dq2, dk2, dv2 = bwd(1)
     dq1, dk1, dv1 = bwd(2)
@@ -167,6 +169,21 @@ def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk, pre):
     assert rel(dq1, back(Qp.grad)) < 2e-2 and rel(dk1, back(K.grad)) < 2e-2 and rel(dv1, back(V.grad)) < 2e-2
     dq4, dk4, dv4 = bwd(2)
     assert torch.equal(dq4, dq1) and torch.equal(dk4, dk1) and torch.equal(dv4, dv1)
+    # chains (crl_attn_bwd_set_chain): a workgroup walks several consecutive key blocks and adds each block's partial dQ to what the blocks
+    # before it left in the slab -- fewer slabs for the reduce, one more bf16 rounding of the running sum per link.  dK / dV do not change
+    # at all; the stream and its C++ form agree bit for bit at every chain length (including one longer than the key blocks there are, and
+    # one that leaves a remainder chain); dQ stays within the single-pass tolerances.
+    nkt = (Nk + 255) // 256
+    dk_c1, dv_c1 = bwd(2, 1)[1:]
+    for chain in sorted({1, 2, 3, nkt + 1}):
+        dqc, dkc, dvc = bwd(2, chain)
+        assert torch.equal(dkc, dk_c1) and torch.equal(dvc, dv_c1), chain
+        assert rel(dqc, dq2) < 1e-2 and rel(dqc, back(Qp.grad)) < 2e-2, chain
+        if pre:
+            dqr, dkr, dvr = bwd(3, chain)
+            assert torch.equal(dqr, dqc) and torch.equal(dkr, dkc) and torch.equal(dvr, dvc), chain
+        if chain == 1 or nkt == 1:
+            assert torch.equal(dqc, bwd(2, 1)[0])
 
 
 # ------------------------------------------------------------------------------------------- GEMM
