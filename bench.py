@@ -418,8 +418,10 @@ def main():
                     cross = (3 * dec_.T + 4 * enc_.N) * args.batch * enc_.D * 2        # q, dO, dQ rows of the targets; k, v, dK, dV rows of the encoder
                     ne, nd = enc_.a['depth'], dec_.L
                     algo = (ne * algo + nd * cross) // (ne + nd)
+                    grid = None                                                      # one grid (chains of key blocks x B x H) for both: the symbol's mean
                     shape_note = (f'mean over the {ne} encoder (N = {enc_.N}) and {nd} cross-attention ({dec_.T} x {enc_.N}) launches of a step, which share one grid; '
-                                  f'the bytes above the algorithmic ones are the ceil(N / 256) bf16 partial-dQ slabs (by design: DESIGN.md (d))')
+                                  f'the bytes above the algorithmic ones are the running partial-dQ slabs: every 256-key block writes its tile rows once and reads '
+                                  f'those of the block before it in its chain (by design: DESIGN.md (d))')
             traffic, src = pmc_traffic(live_prof['kernel'], grid)
             if traffic is not None:
                 live_prof['traffic'] = traffic

@@ -19,7 +19,7 @@ for f in glob.glob('gpurun_out/pmc_attn_*/**/*counter_collection.csv', recursive
     for r in csv.DictReader(open(f)):
         n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']).replace('void ', '').split('(')[0]
         if not n.startswith('attn'): continue
-        if int(r['Grid_Size']) not in (6272 * 256, 3200 * 256) and not n.startswith('attn_dq_reduce'): continue     # ViT-shape launches: 128-row tiles / 256-key blocks x 128 heads
+        if int(r['Grid_Size']) != 6272 * 256 and not n.startswith(('attn_dq_reduce', 'attn_bwd_spx')): continue     # ViT-shape launches: 128-row tiles x 128 heads (the single pass: chains of 256-key blocks x 128 heads)
         agg[n][r['Counter_Name']].append(float(r['Counter_Value']))
 import os
 with open('gpurun_out/%s_pmc_attention.txt' % os.environ.get('TAG', 'r3'), 'w') as out:
