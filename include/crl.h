@@ -177,6 +177,9 @@ int crl_attn_bwd_set_mode(int mode);
  * depend on it; dQ carries one more bf16 rounding of the running sum per link (3.5e-3 instead of 2.6e-3 relative L2 against fp32 at
  * chain 4, 25 key blocks).  crl_attn_bwd_ws_bytes stays sized for chain 1. */
 int crl_attn_bwd_set_chain(int chain);
+/* the chain length the hand-placed single pass would use for Nk keys and BH = B * H heads under the current settings (forced chain,
+ * reserved CUs); host arithmetic only */
+int crl_attn_bwd_chain_for(int Nk, int BH);
 int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                  const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                  const void* d_o, int64_t do_bs, int64_t do_rs, const float* lse, float* delta,

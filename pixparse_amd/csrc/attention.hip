@@ -1210,7 +1210,7 @@ extern "C" int crl_attn_bwd_set_chain(int chain) {
 }
 int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_gemm_set_reserved_cus)
 // Key blocks per workgroup.  A chain of c blocks leaves one slab instead of c (the reduce reads ceil(nkt / c) slabs: ~0.1 of a key block's
-// time each, both proportional to Nq) but its workgroups are c times longer (fewer of them to balance over the CUs) and fewer workgroups
+// time each at 128 heads, both proportional to Nq) but its workgroups are c times longer (fewer of them to balance over the CUs) and fewer workgroups
 // of a head run side by side (the query tiles they share come from L2 only while they do: ~0.06 of a block per extra link measured; priced at 0.1, as each link also adds a bf16 rounding of the running sum).
 // The workgroups start longest first -- nfull = nkt / c full chains per head, then the remainders --; the makespan of that order on the
 // available CUs is simulated once per (nkt, heads, CUs) and the cheapest c kept.  Same-box A/B at cfg-3 (25 key blocks, 128 heads):
@@ -1240,11 +1240,17 @@ static int bwd_chain_length(int nkt, int BH, bool stream) {
     };
     place(nfull * BH, c);
     place(BH, rem);
-    const double cost = makespan + 0.1 * (nfull + (rem ? 1 : 0)) + 0.1 * (c - 1);
+    // a slab costs the reduce (chip-wide, HBM-bound: bytes ~ heads x Nq) 0.1 of a key block's time (one CU: ~ Nq) at 128 heads
+    const double cost = makespan + 0.1 * (BH / 128.0) * (nfull + (rem ? 1 : 0)) + 0.1 * (c - 1);
     if (cost < best - 1e-9) { best = cost; best_c = c; }
   }
   memo_nkt = nkt; memo_bh = BH; memo_cu = ncu; memo_c = best_c;
   return best_c;
+}
+// the chain length crl_attn_bwd would use for Nk keys and B * H heads right now (pure host arithmetic: no GPU needed)
+extern "C" int crl_attn_bwd_chain_for(int Nk, int BH) {
+  if (Nk <= 0 || BH <= 0) { crl_set_error("crl_attn_bwd_chain_for: empty problem"); return -1; }
+  return bwd_chain_length((Nk + 255) / 256, BH, true);
 }
 static bool bwd_fused_wanted(int Nq, int Nk, int causal) {
   if (causal || g_bwd_parts != 7) return false;

@@ -431,6 +431,34 @@ def test_reducer_reserves_cus_for_rccl_by_itself(monkeypatch):
     assert st['buckets'] == 3 and st['bucket_bytes'] == 64 << 20 and st['comm_exposed_ms'] == 0.0 and st['reductions'] == 0
 
 
+def test_attention_backward_chain_length_follows_the_available_cus():
+    """crl_attn_bwd_chain_for: key blocks per workgroup of the single-pass attention backward = argmin of a simulated makespan (longest
+    workgroups first on the CUs not reserved for RCCL) + 0.1 per slab + 0.1 per link.  Host arithmetic only.  cfg-3 (25 key blocks, 128
+    heads): 768 chains of 4 fill 256 CUs three times and the 128 one-block remainders half a round (makespan 13, as without chains, 7 slabs
+    instead of 25); with 16 CUs set aside that shape needs a fourth round, chains of 2 do not; one key block cannot be chained; a forced
+    length is clamped to the key blocks there are; few heads on many CUs are not worth chaining (every link serialises work)."""
+    from pixparse_amd import hip
+    q = lambda nk, bh: hip.query('crl_attn_bwd_chain_for', nk, bh)
+    try:
+        assert q(6189, 128) == 4
+        assert q(200, 128) == 1 and q(256, 8) == 1
+        assert q(6189, 2) == 1                                        # 50 workgroups on 256 CUs: a chain only makes the longest one longer
+        c5 = q(24935, 32)                                             # cfg-5: 98 key blocks, 32 heads
+        assert 2 <= c5 <= 98 and -(-98 // c5) < 98
+        hip.call('crl_gemm_set_reserved_cus', 16)
+        assert q(6189, 128) == 2
+        hip.call('crl_gemm_set_reserved_cus', 0)
+        hip.call('crl_attn_bwd_set_chain', 7)
+        assert q(6189, 128) == 7 and q(300, 128) == 2
+        with pytest.raises(hip.HipLibraryError):
+            hip.call('crl_attn_bwd_set_chain', -1)
+        assert hip.query('crl_attn_bwd_chain_for', 0, 4) == -1
+    finally:
+        hip.call('crl_gemm_set_reserved_cus', 0)
+        hip.call('crl_attn_bwd_set_chain', 0)
+    assert q(6189, 128) == 4
+
+
 def test_bucketed_reducer_two_gloo_ranks():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
