@@ -1211,7 +1211,7 @@ extern "C" int crl_attn_bwd_set_chain(int chain) {
 int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_gemm_set_reserved_cus)
 // Key blocks per workgroup.  A chain of c blocks leaves one slab instead of c (the reduce reads ceil(nkt / c) slabs: ~0.1 of a key block's
 // time each at 128 heads, both proportional to Nq) but its workgroups are c times longer (fewer of them to balance over the CUs) and fewer workgroups
-// of a head run side by side (the query tiles they share come from L2 only while they do: ~0.06 of a block per extra link measured; priced at 0.1, as each link also adds a bf16 rounding of the running sum).
+// of a head run side by side (the query tiles they share come from L2 only while they do).
 // The workgroups start longest first -- nfull = nkt / c full chains per head, then the remainders --; the makespan of that order on the
 // available CUs is simulated once per (nkt, heads, CUs) and the cheapest c kept.  Same-box A/B at cfg-3 (25 key blocks, 128 heads):
 // c = 3 / 4 / 6 within noise of each other, -2.5 ms per step against c = 1, c = 12 half of that (profiles/r4_attn_chain.txt).
@@ -1221,11 +1221,20 @@ static int bwd_chain_length(int nkt, int BH, bool stream) {
   static int memo_nkt = 0, memo_bh = 0, memo_cu = 0, memo_c = 1;
   const int ncu = crl_gemm_cus();
   if (nkt == memo_nkt && BH == memo_bh && ncu == memo_cu) return memo_c;
+  // in units of one key block's time on one CU (~ Nq): the stream slows by ~0.6 % per link (fewer workgroups of a head side by side: c = 12
+  // against 6 at cfg-3), a slab costs the reduce (chip-wide, HBM-bound: bytes ~ heads x Nq) 0.1 at 128 heads, and a link is charged 0.03
+  // more for the bf16 rounding it adds to the running sum (ties go to the shorter chain)
+  auto price = [&](double makespan, int c, int nslab) { return makespan * (1.0 + 0.006 * (c - 1)) + 0.1 * (BH / 128.0) * nslab + 0.03 * (c - 1); };
   double best = 1e30;
   int best_c = 1;
   std::vector<int> busy((size_t)ncu);
-  for (int c = 1; c <= nkt; ++c) {
+  for (int c = 1; c <= nkt && c <= 32; ++c) {
     const int nfull = nkt / c, rem = nkt % c;
+    if ((int64_t)nfull * BH > 16 * (int64_t)ncu) {      // many rounds: the last one hardly matters, and the simulation would take long
+      const double cost = price((double)nkt * BH / ncu + c, c, nfull + (rem ? 1 : 0));      // + c: one workgroup of slack
+      if (cost < best - 1e-9) { best = cost; best_c = c; }
+      continue;
+    }
     // workgroups start in index order on the CU that frees up first (a min-heap over the CUs' finish times)
     std::fill(busy.begin(), busy.end(), 0);
     auto later = [](int x, int y) { return x > y; };
@@ -1240,8 +1249,7 @@ static int bwd_chain_length(int nkt, int BH, bool stream) {
     };
     place(nfull * BH, c);
     place(BH, rem);
-    // a slab costs the reduce (chip-wide, HBM-bound: bytes ~ heads x Nq) 0.1 of a key block's time (one CU: ~ Nq) at 128 heads
-    const double cost = makespan + 0.1 * (BH / 128.0) * (nfull + (rem ? 1 : 0)) + 0.1 * (c - 1);
+    const double cost = price(makespan, c, nfull + (rem ? 1 : 0));
     if (cost < best - 1e-9) { best = cost; best_c = c; }
   }
   memo_nkt = nkt; memo_bh = BH; memo_cu = ncu; memo_c = best_c;

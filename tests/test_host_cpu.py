@@ -433,7 +433,7 @@ def test_reducer_reserves_cus_for_rccl_by_itself(monkeypatch):
 
 def test_attention_backward_chain_length_follows_the_available_cus():
     """crl_attn_bwd_chain_for: key blocks per workgroup of the single-pass attention backward = argmin of a simulated makespan (longest
-    workgroups first on the CUs not reserved for RCCL) + 0.1 per slab + 0.1 per link.  Host arithmetic only.  cfg-3 (25 key blocks, 128
+    workgroups first on the CUs not reserved for RCCL), stretched by 0.6 % per link, + 0.1 per slab (at 128 heads) + 0.03 per link.  Host arithmetic only.  cfg-3 (25 key blocks, 128
     heads): 768 chains of 4 fill 256 CUs three times and the 128 one-block remainders half a round (makespan 13, as without chains, 7 slabs
     instead of 25); with 16 CUs set aside that shape needs a fourth round, chains of 2 do not; one key block cannot be chained; a forced
     length is clamped to the key blocks there are; few heads on many CUs are not worth chaining (every link serialises work)."""
