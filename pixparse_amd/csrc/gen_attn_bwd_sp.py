@@ -12,11 +12,17 @@
   v[128:159]  Q / dO row fragments of the current 32-query block (each feeds both key blocks)
   v[160:191]  Q^T / dO^T transposed fragments of the current 32-query block (each feeds both key blocks)
   v[192:207]  dS^T fragments for the dQ product       v[208:223]  dQ^T accumulator
-  v[224:255]  left to the compiler: the per-lane LDS / global offsets it passes in as operands
+  v[224:255]  left to the compiler: the 26 per-lane LDS / global offsets it passes in as operands (the K / V fragment and dK / dV store
+              offsets are computed in the stream from the lane id: the wrapper's key-block loop needs the rest of these 32 registers)
 
 Per 64-query tile a wave issues 80 MFMAs (32 S / dP, 32 dV / dK, 16 dQ of the PREVIOUS tile) as a fixed backbone; everything else --
-112 LDS instructions, 64 v_exp, 64 multiplies, 72 conversions, 5 LDS-DMA pieces, 2 slab stores (16 bytes per lane after a
-v_permlane32_swap exchange), counted waits -- is assigned to one of the 80 MFMA gaps by the tables below.  The loop is unrolled six-fold
+114 LDS instructions, 64 v_exp, 64 multiplies, 72 conversions, 16 unpack operations, 7 LDS-DMA pieces, 2 slab stores (16 bytes per lane
+after a v_permlane32_swap exchange), counted waits -- is assigned to one of the 80 MFMA gaps by the tables below.
+CHAINS: the wrapper runs this statement once per key block of a chain (attention.hip: attn_bwd_spx_kernel); the dQ of a tile starts from
+the running partial the previous key blocks of the chain left in the slab: DMA'd into a ring of three 8-KiB buffers above the dS buffers
+two tiles ahead (dma_part: the youngest memory operations of a pass, the rendezvous leaves them in flight), read back at the end of the
+pass before its use through addresses that undo the store's lane exchange (load_part), unpacked to fp32 in the first gaps of the next
+pass (unpack_part) = the C operand of the tile's first dQ MFMA.  The first key block of a chain reads through a descriptor without records.  The loop is unrolled six-fold
 (ring of 3 x dS double buffer): every LDS address of a pass is a per-lane base register + an immediate.  Software pipeline over 32 x 32 blocks n = (qb, kb):
   slot n:  MFMAs  S / dP of block n + 1  |  dV / dK of block n - 1  |  a quarter of dQ(t - 1)     VALU: exp / mul / cvt of block n
 so no MFMA ever waits for VALU work of its own slot.  One s_barrier per tile (top of the iteration): dS of tile t - 1 complete, ring
