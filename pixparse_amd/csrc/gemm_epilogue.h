@@ -32,8 +32,18 @@ typedef unsigned epi_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ epi_u4 epi_ld(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
-__device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, uint32_t off, epi_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0); }
+#ifndef G_EPI_LD_AUX
+#define G_EPI_LD_AUX 0    // cache-policy bits of the epilogue's tile loads / stores (gfx942+: 1 = sc0, 2 = nt, 16 = sc1): A/B knobs
+#endif
+#ifndef G_EPI_ST_AUX
+#define G_EPI_ST_AUX 0
+#endif
+__device__ __forceinline__ epi_u4 epi_ld(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, G_EPI_LD_AUX); }
+#ifndef G_EPI_SAVE_AUX
+#define G_EPI_SAVE_AUX 0   // ... of the store of the GELU pre-activation (read again only by the backward, a whole forward + half a backward later)
+#endif
+__device__ __forceinline__ void epi_st(__amdgpu_buffer_rsrc_t r, uint32_t off, epi_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, G_EPI_ST_AUX); }
+__device__ __forceinline__ void epi_st_saved(__amdgpu_buffer_rsrc_t r, uint32_t off, epi_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, G_EPI_SAVE_AUX); }
 
 #ifndef G_EPI_XPOSE
 #define G_EPI_XPOSE 1
@@ -165,7 +175,7 @@ __device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc
           const uint32_t h00 = pack_bf2v(v[0][0]), h01 = pack_bf2v(v[0][1]), h10 = pack_bf2v(v[1][0]), h11 = pack_bf2v(v[1][1]);
           x0 = h00; x1 = h01; y0 = h10; y1 = h11;
           swap_strips(x0, x1, y0, y1);
-          epi_st(rA, offA(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
+          epi_st_saved(rA, offA(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
           x0 = pack_bf2v(gelu2(unpack_bf2(h00))); x1 = pack_bf2v(gelu2(unpack_bf2(h01)));
           y0 = pack_bf2v(gelu2(unpack_bf2(h10))); y1 = pack_bf2v(gelu2(unpack_bf2(h11)));
           swap_strips(x0, x1, y0, y1);
