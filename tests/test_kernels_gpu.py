@@ -109,15 +109,16 @@ def test_gemm_column_scale(dev):
 
 # ------------------------------------------------------------------------------------------- attention backward, single-pass form
 @pytest.mark.parametrize('B,H,Nq,Nk,pre', [(1, 2, 300, 700, True), (2, 1, 64, 512, True), (1, 2, 100, 45, True), (1, 2, 1023, 1300, True),
-                                           (2, 2, 577, 577, True), (1, 1, 2100, 1100, True), (1, 2, 300, 700, False), (1, 1, 130, 260, False)])
+                                           (2, 2, 577, 577, True), (1, 1, 2100, 1100, True), (1, 2, 300, 700, False), (1, 1, 130, 260, False),
+                                           (2, 4, 130, 600, True)])
 def test_attention_backward_single_pass_mode(dev, B, H, Nq, Nk, pre):
     """crl_attn_bwd_set_mode(2): dK, dV and dQ from ONE recomputation of S / dP (5 MFMA products), dQ as a sum of per-key-block bf16 slabs
     reduced in fixed order.  pre: q prescaled = the hand-placed instruction stream (attn_bwd_spx_kernel), else the C++ form of the same
     algorithm; mode 3 runs the C++ form on the prescaled problem too and must agree with the stream BIT FOR BIT.  Against the two-pass
     form: dV bit for bit, dK to 1e-4, dQ within the extra bf16 rounding of the partials; against fp32 torch: the tolerance of the two-pass
     tests; two runs bit-identical.  Shapes cover a ragged last key block, fewer keys than one workgroup owns (256), ragged query tiles,
-    more tiles than the ring / unroll period, strided q | k | v views and the cross-attention aspect ratio; the last prescaled shape is
-    long enough for mode 0 (auto) to pick the single pass by itself."""
+    more tiles than the ring / unroll period, strided q | k | v views and the cross-attention aspect ratio; the (1, 1, 2100, 1100) shape is
+    long enough for mode 0 (auto) to pick the single pass by itself; the last one has B * H = 8 heads (the XCD-aware workgroup order)."""
     from pixparse_amd import hip, ops
     D, scale = H * 64, 0.125
     c = scale * ops.LOG2E if pre else 1.0
