@@ -48,12 +48,15 @@ _calibrated = {}
 
 def gemm_calibrate(device, force: bool = False):
     """one-off per process and device: refit the wave-quantisation cost model of the persistent GEMMs to what THIS device sustains
-    (crl_gemm_calibrate; synchronises).  PIXPARSE_AMD_GEMM_CALIBRATE=0 keeps the built-in constants.  Returns (a_us, b_us, calibrated)."""
+    (crl_gemm_calibrate; synchronises).  OPT-IN since round 5 (PIXPARSE_AMD_GEMM_CALIBRATE=1, or force=True): the fitted constants decide
+    where the wave-quantisation cut falls, i.e. which rows take the split-contraction path with its different summation order, so a default-on
+    timing fit made the bits of every large GEMM depend on measurement noise (run to run, rank to rank, across a resume) for no
+    measured gain (244.3 vs 244.0 ms).  Returns (a_us, b_us, calibrated)."""
     import ctypes
     import os
     key = str(device)
     # (two ranks sharing one device -- CRL_DEBUG_SHARED_GPU, a validation aid -- would time each other's launches: built-in constants there)
-    if (key not in _calibrated or force) and os.environ.get('PIXPARSE_AMD_GEMM_CALIBRATE', '1') != '0' and os.environ.get('CRL_DEBUG_SHARED_GPU', '0') != '1':
+    if (force or (key not in _calibrated and os.environ.get('PIXPARSE_AMD_GEMM_CALIBRATE', '0') == '1')) and os.environ.get('CRL_DEBUG_SHARED_GPU', '0') != '1':
         nbytes = hip.query('crl_gemm_calibrate_ws_bytes')
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)      # its own buffer: released again right away
         rc = hip.load().crl_gemm_calibrate(_p(ws), nbytes, _stream())

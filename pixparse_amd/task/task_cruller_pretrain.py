@@ -149,7 +149,7 @@ class TaskCrullerPretrain(TaskTrain):
                                            warmup_t=self.num_warmup_intervals * self.num_steps_per_interval,
                                            warmup_lr_init=opt.warmup_learning_rate)
         self.scheduler.step_update(0)
-        # the persistent GEMMs' wave-quantisation model is refitted to what THIS device sustains (one-off, ~20 ms; PIXPARSE_AMD_GEMM_CALIBRATE=0: built-in)
+        # the persistent GEMMs' wave-quantisation model: built-in constants (reproducible bits); PIXPARSE_AMD_GEMM_CALIBRATE=1 refits it to what THIS device sustains
         from .. import ops as _ops
         self.gemm_model = _ops.gemm_calibrate(self.device_env.device)
         # hipGraph replay of the micro-step: legal when nothing the step launches depends on host state -- the LR and the bias
