@@ -10,10 +10,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcruller_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm2x.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'dropout.hip', 'debug.hip', 'capi.cpp']
-HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", "attn_bwd_sp_body.inc", os.path.join('..', '..', 'include', 'crl.h')]
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm4w.hip', 'gemm2x.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'dropout.hip', 'debug.hip', 'capi.cpp']
+HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", "attn_bwd_sp_body.inc", "gemm4w_body_nt.inc", "gemm4w_body_nn.inc", "gemm4w_body_tn.inc", os.path.join('..', '..', 'include', 'crl.h')]
 # generated sources: (generator script, output) -- the output is committed; it is regenerated when the script is newer
-GENERATED = [('gen_attn_bwd_sp.py', 'attn_bwd_sp_body.inc')]
+GENERATED = [('gen_attn_bwd_sp.py', 'attn_bwd_sp_body.inc'), ('gen_gemm4w.py', 'gemm4w_body_nt.inc')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # per-file extras: hipcc's SLP vectoriser packs the softmax / dS multiplies of the attention kernels into v_pk_mul_f32 on
 # misaligned register pairs and then spends ~25 v_mov / v_perm / v_alignbit per 32x32 block re-assembling the bf16 MFMA
@@ -21,7 +21,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-res
 # the persistent GEMMs pull their next tile with ONE lane's returning atomic whose answer is consumed a whole K loop later; LLVM's
 # atomic optimizer would rewrite it into a wave-aggregated add + readfirstlane and wait for it on the spot.
 _NO_ATOMIC_OPT = ['-mllvm', '-amdgpu-atomic-optimizer-strategy=None']
-EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'gemm256.hip': _NO_ATOMIC_OPT, 'gemm2x.hip': _NO_ATOMIC_OPT}
+EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'gemm256.hip': _NO_ATOMIC_OPT, 'gemm2x.hip': _NO_ATOMIC_OPT, 'gemm4w.hip': _NO_ATOMIC_OPT}
 
 
 def _hipcc():

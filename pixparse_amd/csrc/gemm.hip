@@ -221,6 +221,7 @@ int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
 }  // namespace
 
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
+int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
 int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t s);
 
 // ---- launch geometry of the persistent kernels + the ticket-counter pool of the dynamic tile scheduler (gemm_common.h) ----
@@ -270,6 +271,19 @@ extern "C" int crl_gemm_set_schedule(int dynamic) {
 #endif
 struct Plan { bool big; int nsplit; int64_t chunk; };
 static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel, 3 force the 256x128 two-per-CU kernel (tests, A/B)
+// which 256x256 kernel serves the "big" launches: 0 = gemm256.hip (8 waves, two per SIMD), 1 = gemm4w.hip (4 waves, one per SIMD: round 5)
+#ifndef G_BIG_4W
+#define G_BIG_4W 1
+#endif
+static int g_big4w = G_BIG_4W;
+static int big_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
+  return g_big4w ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
+}
+extern "C" int crl_gemm_set_big_kernel(int four_waves) {
+  if (four_waves != 0 && four_waves != 1) { crl_set_error("crl_gemm_set_big_kernel: 0 = gemm256 (8 waves), 1 = gemm4w (4 waves)"); return -1; }
+  g_big4w = four_waves;
+  return 0;
+}
 #ifndef G_AUTO_2X
 #define G_AUTO_2X 1      // auto policy: very wide NT outputs (the LM head: N = 50304) go to the 256x128 two-workgroups-per-CU kernel
 #endif                   // (gemm2x.hip): same-box A/B +8 % there, +15 % at 8192^3; the K = 1024 encoder shapes are faster on the
@@ -533,7 +547,7 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   if (p.nsplit > 1) {
     GemmArgs b = a;
     b.C = ws; b.ldc = (int)N; b.slab_stride = (size_t)M * N;
-    if (int rc = p.big ? crl_gemm256_launch(CRL_TN, CRL_EPI_F32, b, p.nsplit, s) : launch_epi<CRL_TN>(b, CRL_EPI_F32, bk, p.nsplit, s)) return rc;
+    if (int rc = p.big ? big_launch(CRL_TN, CRL_EPI_F32, b, p.nsplit, s) : launch_epi<CRL_TN>(b, CRL_EPI_F32, bk, p.nsplit, s)) return rc;
     const size_t n4 = (size_t)M * N / 4;
     splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc,
                                                                     epilogue == CRL_EPI_F32_ACC);
@@ -555,11 +569,11 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   };
   if (p.big) {
     const int64_t best_r = quant_rows(layout, epilogue, M, N, K);
-    if (best_r < 0) return crl_gemm256_launch(layout, epilogue, a, 1, s);
+    if (best_r < 0) return big_launch(layout, epilogue, a, 1, s);
     const int64_t m1 = 256 * best_r;
     GemmArgs big = a;
     big.M = (int)m1; big.ntm = (int)best_r;
-    if (int rc = crl_gemm256_launch(layout, epilogue, big, 1, s)) return rc;
+    if (int rc = big_launch(layout, epilogue, big, 1, s)) return rc;
     GemmArgs rest = a;
     const bool c32 = epilogue >= CRL_EPI_F32_RESID;
     rest.A = a.A + m1 * lda;

@@ -331,14 +331,15 @@ def test_gemm_strided_views_and_errors(dev):
         ops.linear_fwd(rnd((8, 40), dev, 1, 1, BF16), rnd((8, 40), dev, 1, 2, BF16), None, torch.empty(8, 8, dtype=BF16, device=dev))  # K % 32
 
 
-@pytest.mark.parametrize('policy', [2, 3])
+@pytest.mark.parametrize('policy,big', [(2, 1), (2, 0), (3, 1)])
 @pytest.mark.parametrize('K', [64, 128, 192, 448])
-def test_gemm_256_kernel_all_layouts(dev, K, policy):
-    """the 256x256 8-phase kernel (policy 2) and the 256x128 two-workgroups-per-CU kernel (policy 3: NT / NN, the wgrad
-    layout stays on the 256x256 kernel) forced on ragged shapes (odd / even / single K-tile counts, ragged M and N tiles),
-    against fp32 torch; then the split-K wgrad path through fp32 slabs"""
+def test_gemm_256_kernel_all_layouts(dev, K, policy, big):
+    """the two 256x256 kernels (policy 2: big = 1 the 4-wave one-wave-per-SIMD kernel of round 5, big = 0 the 8-wave 8-phase kernel) and the
+    256x128 two-workgroups-per-CU kernel (policy 3: NT / NN, the wgrad layout stays on the 256x256 kernel) forced on ragged shapes (odd / even /
+    single K-tile counts, ragged M and N tiles), against fp32 torch; then the split-K wgrad path through fp32 slabs"""
     from pixparse_amd import hip, ops
     M, N = 600, 520
+    hip.call('crl_gemm_set_big_kernel', big)
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
@@ -376,6 +377,60 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy):
         close(dw, 3.0 + dy.float().t() @ x.float(), 2e-3, 5e-2, '256 TN acc')
     finally:
         hip.call('crl_gemm_set_policy', 0)
+        hip.call('crl_gemm_set_big_kernel', 1)
+
+
+@pytest.mark.parametrize('M,N,K', [(600, 520, 192), (256 * 9 + 40, 1024, 1024), (1024, 768, 64), (4096, 4096, 4096 + 64)])
+def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
+    """gemm4w.hip (4 waves, one per SIMD, hand-placed main loop) against gemm256.hip (8 waves): every accumulator sums the same products in the
+    same order and the epilogue arithmetic is the same, so all three layouts and all six epilogues agree BIT FOR BIT -- ragged M / N tiles, one /
+    odd / even K-tile counts, persistent launches (more tiles than CUs) and split-K weight gradients included"""
+    from pixparse_amd import hip, ops
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    dy = rnd((M, N), dev, 1.0, 4, BF16)
+    h = rnd((M, K), dev, 1.0, 6, BF16)
+    y0 = rnd((M, N), dev, 1.0, 5)
+    acc0 = rnd((M, K), dev, 1.0, 7)
+    NC = N - N % 32                      # NN: the contraction (N) must be a multiple of 32
+    KC = K - K % 64 if K % 64 else K
+
+    def run():
+        out = torch.empty(M, N, dtype=BF16, device=dev); pre = torch.empty(M, N, dtype=BF16, device=dev); g = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, out, colscale=0.25, colscale_cols=min(N, 256))
+        ops.linear_fwd(x, w, bias, g, ops.EPI_BF16_GELU, aux=pre)
+        y = y0.clone()
+        ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
+        dx = torch.empty(M, K, dtype=BF16, device=dev); dxg = torch.empty(M, K, dtype=BF16, device=dev)
+        ops.linear_dgrad(dy[:, :NC], w[:NC], dx)
+        ops.linear_dgrad(dy[:, :NC], w[:NC], dxg, ops.EPI_BF16_DGELU, aux=h)
+        accb = acc0.clone()
+        ops.linear_dgrad(dy[:, :NC], w[:NC], accb, ops.EPI_F32_ACC)
+        dw = torch.full((N, K), 3.0, device=dev)
+        ops.linear_wgrad(dy, x, dw, accumulate=True)
+        dw2 = torch.empty(N, K, device=dev)
+        ops.linear_wgrad(dy, x, dw2, accumulate=False)
+        return out, pre, g, y, dx, dxg, accb, dw, dw2
+
+    names = ['NT bf16 + colscale', 'NT gelu aux', 'NT gelu', 'NT resid', 'NN', 'NN dgelu', 'NN f32 acc', 'TN acc', 'TN store']
+    hip.call('crl_gemm_set_policy', 2)
+    try:
+        hip.call('crl_gemm_set_big_kernel', 0)
+        want = run()
+        hip.call('crl_gemm_set_big_kernel', 1)
+        got = run()
+        again = run()
+    finally:
+        hip.call('crl_gemm_set_policy', 0)
+        hip.call('crl_gemm_set_big_kernel', 1)
+    ref = x.float() @ w.float().t() + bias.to(BF16).float()
+    ref[:, :min(N, 256)] *= 0.25
+    close(got[0], ref, 1e-2, 1e-2, '4w NT vs fp32')
+    close(got[8], dy.float().t() @ x.float(), 2e-3, 0.2, '4w TN vs fp32')
+    for n, a, b, c in zip(names, want, got, again):
+        assert torch.equal(a, b), f'{n}: 4-wave kernel differs from the 8-wave kernel (max abs {(a.float() - b.float()).abs().max().item():.3e})'
+        assert torch.equal(b, c), f'{n}: 4-wave kernel is not reproducible'
 
 
 def test_gemm_dynamic_tile_schedule(dev):
