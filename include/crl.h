@@ -55,9 +55,10 @@ size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t
  * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent
  * workgroups per CU: epilogues overlap main loops) for the NT / NN layouts whenever legal. */
 int crl_gemm_set_policy(int policy);
-/* which 256x256 kernel serves the big launches: 1 (default) = 4 waves, one per SIMD, 128x128 per wave, hand-placed main loop (gemm4w.hip,
- * round 5); 0 = the 8-wave 8-phase kernel of rounds 1-4 (gemm256.hip).  Same results bit for bit; tests / same-box A-B.  Process-wide. */
-int crl_gemm_set_big_kernel(int four_waves);
+/* which 256x256 kernel serves the big launches: 2 (default) = per launch -- the 4-wave one-wave-per-SIMD kernel with the hand-placed main loop
+ * (gemm4w.hip, round 5) where a workgroup walks >= 32 K tiles behind a store-only epilogue (weight gradients, long-K dgrads), else the 8-wave
+ * 8-phase kernel (gemm256.hip); 1 / 0 force one of them.  Same results bit for bit; tests / same-box A-B.  Process-wide. */
+int crl_gemm_set_big_kernel(int which);
 /* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
    < 0 = never cut.  Process-wide. */
 int crl_gemm_set_quant_cost(float c);

@@ -271,17 +271,24 @@ extern "C" int crl_gemm_set_schedule(int dynamic) {
 #endif
 struct Plan { bool big; int nsplit; int64_t chunk; };
 static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel, 3 force the 256x128 two-per-CU kernel (tests, A/B)
-// which 256x256 kernel serves the "big" launches: 0 = gemm256.hip (8 waves, two per SIMD), 1 = gemm4w.hip (4 waves, one per SIMD: round 5)
+// which 256x256 kernel serves the "big" launches: 0 = gemm256.hip (8 waves, two per SIMD), 1 = gemm4w.hip (4 waves, one per SIMD: round 5),
+// 2 = per launch (default).  Same-box table (profiles/r5_gemm4w_grouped.txt): the 4-wave main loop is 3-16 % faster wherever a workgroup walks
+// >= 32 K tiles behind a store-only epilogue (every weight gradient: +12-16 %, the K = 3072 / 4096 dgrads: +3-6 %, fc2 plain: +3 %), equal at
+// K = 1024 (both prologue / epilogue bound) and SLOWER behind the tile-reading and VALU-heavy epilogues (fp32 residual 0.52 vs 0.66 PF/s, GELU
+// 0.85 vs 0.88): a wave alone on its SIMD has half the loads in flight and half the VALU issue rate of two waves.
 #ifndef G_BIG_4W
-#define G_BIG_4W 1
+#define G_BIG_4W 2
 #endif
 static int g_big4w = G_BIG_4W;
 static int big_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
-  return g_big4w ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
+  const bool store_only = epi == CRL_EPI_BF16 || epi == CRL_EPI_F32 || epi == CRL_EPI_F32_ACC;
+  const int nk_wg = nsplit > 1 ? a.kchunk : (a.K + 63) / 64;
+  const bool four = g_big4w == 1 || (g_big4w == 2 && store_only && nk_wg >= 32);
+  return four ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
 }
-extern "C" int crl_gemm_set_big_kernel(int four_waves) {
-  if (four_waves != 0 && four_waves != 1) { crl_set_error("crl_gemm_set_big_kernel: 0 = gemm256 (8 waves), 1 = gemm4w (4 waves)"); return -1; }
-  g_big4w = four_waves;
+extern "C" int crl_gemm_set_big_kernel(int which) {
+  if (which < 0 || which > 2) { crl_set_error("crl_gemm_set_big_kernel: 0 = gemm256 (8 waves), 1 = gemm4w (4 waves), 2 = per launch"); return -1; }
+  g_big4w = which;
   return 0;
 }
 #ifndef G_AUTO_2X

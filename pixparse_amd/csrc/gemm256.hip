@@ -78,8 +78,10 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
   int m0, n0;
   auto set_tile = [&](int l) {
     const int t = xcd_remap(l, ntiles);
-    m0 = (t / g.ntn) * 256;
-    n0 = (t % g.ntn) * 256;
+    int tm, tn;
+    tile_coords(t, g.ntm, g.ntn, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * 256;
   };
   set_tile(logical);
 

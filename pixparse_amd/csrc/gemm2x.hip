@@ -124,7 +124,9 @@ __global__ __launch_bounds__(T2, 2) void gemm2x_kernel(const GemmArgs g) {
   while (logical >= 0 && logical < ntiles) {   // persistent: two resident workgroups per CU walk the tiles
   {
     const int t_id = xcd_remap(logical, ntiles);
-    m0 = (t_id / g.ntn) * 256; n0 = (t_id % g.ntn) * 128;
+    int tm, tn;
+    tile_coords(t_id, g.ntm, g.ntn, tm, tn);       // grouped order (gemm_common.h): 8 tile rows x a few columns share panels in one XCD's L2
+    m0 = tm * 256; n0 = tn * 128;
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)

@@ -4,8 +4,8 @@
 // the LDS 75 % busy (24 ds_read_b128 per 64 MFMAs and wave, two waves per SIMD); on the same box the vendor's 4-wave 256x256x64 kernel
 // sustains 1.64 PF/s against 1.24 (profiles/r5_yardstick.txt) -- the loop is held down by energy per FLOP, not by issue slots.  Here a
 // wave owns a 128x128 quadrant of the tile (256 accumulator registers in the AGPR half of its 512-entry file) and reads one A and one B
-// half-tile per K tile: 32 ds_read_b128 per 128 MFMAs, 1.5 x fewer LDS bytes per FLOP, no partner wave to arbitrate with, 3 barriers per
-// K tile of 128 MFMAs instead of 8 per 64.  The main loop is ONE generated asm statement (gen_gemm4w.py -> gemm4w_body_{nt,nn,tn}.inc:
+// half-tile per K tile: 32 ds_read_b128 per 128 MFMAs, 1.5 x fewer LDS bytes per FLOP, no partner wave to arbitrate with, 2 barriers per
+// K tile of 128 MFMAs instead of 8 per 64; all 160 KiB of LDS as a ring of five 32-KiB operand pairs, two K tiles of look-ahead.  The main loop is ONE generated asm statement (gen_gemm4w.py -> gemm4w_body_{nt,nn,tn}.inc:
 // register map, schedule, hazards); this file is the persistent tile walk around it (dynamic ticket scheduler of gemm_common.h), the
 // staging of the first two K tiles of every output tile (issued under the previous tile's epilogue) and the epilogue, which receives the
 // accumulators as physical-register asm outputs and applies the arithmetic of gemm_epilogue.h operation for operation (results are
@@ -179,20 +179,22 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
   const int wr = wave >> 1, wc = wave & 1;
 
   const int ntiles = g.ntm * g.ntn;
-  __shared__ int s_next, s_list;
+  // dynamic tile schedule (gemm_common.h): thread 0 pulls the tickets; the tile index travels to the other waves through the first word of the
+  // LDS ring, which is idle at every output-tile boundary (all 160 KiB belong to the ring: there is no room for a static __shared__ word)
   const bool dyn = g.sched != nullptr;
   uint32_t ticket = 0;
+  int my_list = 0;
   int logical = blockIdx.x;
   if (dyn) {
     if (tid == 0) {
-      int my_list = sched_xcd();
+      my_list = sched_xcd();
       ticket = sched_pull(g.sched + my_list);
-      s_next = sched_resolve(g.sched, my_list, ticket, ntiles);
-      s_list = my_list;
+      *reinterpret_cast<volatile int*>(smem) = sched_resolve(g.sched, my_list, ticket, ntiles);
     }
     __syncthreads();
-    logical = __builtin_amdgcn_readfirstlane(s_next);
-    if (logical < 0) {
+    logical = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+    __syncthreads();
+    if (logical < 0) {                // started after the resident workgroups had emptied the queue
       if (tid == 0) sched_leave(g.sched, gridDim.x);
       return;
     }
@@ -200,8 +202,10 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
   int m0, n0;
   auto set_tile = [&](int l) {
     const int t = xcd_remap(l, ntiles);
-    m0 = (t / g.ntn) * 256;
-    n0 = (t % g.ntn) * 256;
+    int tm, tn;
+    tile_coords(t, g.ntm, g.ntn, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * 256;
   };
   set_tile(logical);
 
@@ -235,18 +239,32 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
     const bool live = tile < nk;
     const u32x4 sa = live ? ra : rzero, sb = live ? rb : rzero;
     const uint32_t oa = offA_of(tile), ob = offB_of(tile);
+    // ring of five pair-slots of 32 KiB: A(t) -> slot 2 t mod 5, B(t) -> slot (2 t + 1) mod 5; half h at + 16 KiB, piece it at + 4 KiB
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        dma16(sa, s_ldsw + (uint32_t)((2 * (h ? 3 : 0) + tile) * 16384 + it * 4096), voffA, oa + h * s_halfA + it * s_itA);
-        dma16(sb, s_ldsw + (uint32_t)((2 * (h ? 2 : 1) + tile) * 16384 + it * 4096), voffB, ob + h * s_halfB + it * s_itB);
+        dma16(sa, s_ldsw + (uint32_t)(((2 * tile) % 5) * 32768 + h * 16384 + it * 4096), voffA, oa + h * s_halfA + it * s_itA);
+        dma16(sb, s_ldsw + (uint32_t)(((2 * tile + 1) % 5) * 32768 + h * 16384 + it * 4096), voffB, ob + h * s_halfB + it * s_itB);
       }
   };
 
+#ifndef G4_CU_STAGGER
+#define G4_CU_STAGGER 0
+#endif
+#ifndef G4_CUS_KT
+#define G4_CUS_KT 10      // s_sleep units (64 clocks) per K tile: about half of a K tile's ~1.3 us
+#endif
+  // experiment (default off): half of the persistent workgroups start half a tile period late, so that the tile-sized epilogue traffic of one
+  // half of the chip falls under the K loops of the other half instead of every CU reaching its epilogue at the same time
+  if (G4_CU_STAGGER && gridDim.y == 1 && ntiles >= 2 * (int)gridDim.x && ((blockIdx.x >> 3) & 1)) {
+    constexpr int base = EPI == CRL_EPI_BF16 ? 60 : EPI == CRL_EPI_BF16_GELU ? 120 : EPI == CRL_EPI_BF16_DGELU ? 120 : 200;
+    const int n = nk_all * G4_CUS_KT + base;
+    for (int i = 0; i < n; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
   stage(0); stage(1);
   for (;;) {   // output tiles of this workgroup
-    if (dyn && tid == 0) ticket = sched_pull(g.sched + s_list);   // the answer arrives under the K loop
+    if (dyn && tid == 0) ticket = sched_pull(g.sched + my_list);   // the answer arrives under the K loop
     // ---- operands of the stream (per-lane values derived from an opaque copy of the thread index: nothing of this may be hoisted into
     // registers that live across the epilogue)
     int t2 = threadIdx.x;
@@ -257,8 +275,8 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
     else { const int r = t2 >> 3; voffA = (uint32_t)r * g.lda * 2u + (uint32_t)(((t2 & 7) ^ km_swz<64>(r)) * 16); }
     if constexpr (B_TR) { const int kr = t2 >> 4; voffB = (uint32_t)kr * g.ldb * 2u + (uint32_t)(((t2 & 15) ^ tr_swz(kr)) * 16); }
     else { const int r = t2 >> 3; voffB = (uint32_t)r * g.ldb * 2u + (uint32_t)(((t2 & 7) ^ km_swz<64>(r)) * 16); }
-    // fragment read addresses (unit (slot, buffer) at (2 slot + buffer) * 16384; buffer, row group / k-step offsets are immediates)
-    const uint32_t unitA = smem_base + (uint32_t)(wr ? 3 : 0) * 32768u, unitB = smem_base + (uint32_t)(wc ? 2 : 1) * 32768u;
+    // fragment read addresses at ring offset 0 (the stream adds the pair-slot, row group and k-step offsets): the wave's half of an A / B pair
+    const uint32_t unitA = smem_base + (uint32_t)wr * 16384u, unitB = smem_base + (uint32_t)wc * 16384u;
     //   KM: row 16 i + li, 16-byte slot (4 ks + lq) ^ ((li >> 1) & 7)
     const uint32_t km_k0 = (uint32_t)(li * 128 + (((0 + lq) ^ ((li >> 1) & 7)) << 4)), km_k1 = (uint32_t)(li * 128 + (((4 + lq) ^ ((li >> 1) & 7)) << 4));
     //   TR: lane (g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3): k row 8 g + q (+ 32 ks, + 4 for the second read), column 16 j + 4 p
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
     auto tr_addr = [&](int j) { return (uint32_t)((8 * tg + tq) * 256 + ((((2 * j) ^ tsw) + (tp >> 1)) << 4) + 8 * (tp & 1)); };
     u32x4 srdA = ra, srdB = rb;
     uint32_t s_offA = offA_of(2), s_offB = offB_of(2);
-    uint32_t s_live = (uint32_t)(nk - 2), s_cnt = (uint32_t)((nk + 1) >> 1), s_t;
+    uint32_t s_live = (uint32_t)(nk - 2), s_cnt = (uint32_t)nk, s_t;
     f32x4 c[8][8];
     if constexpr (LAYOUT == CRL_NT) {
       uint32_t arAk0 = unitA + km_k0, arAk1 = unitA + km_k1, arBk0 = unitB + km_k0, arBk1 = unitB + km_k1;
@@ -284,18 +302,16 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
                arBt4 = unitB + tr_addr(4), arBt5 = unitB + tr_addr(5), arBt6 = unitB + tr_addr(6), arBt7 = unitB + tr_addr(7);
 #include "gemm4w_body_tn.inc"
     }
-    // ---- next tile: published by wave 0 before the barrier that lets everybody read it
+    // ---- next tile (the stream ends behind a barrier: the ring is idle): thread 0 publishes it through the first word of the LDS
+    int next_logical = logical + (int)gridDim.x;
     if (dyn) {
-      if (tid == 0) {
-        int my_list = s_list;
-        s_next = sched_resolve(g.sched, my_list, ticket, ntiles);
-        s_list = my_list;
-      }
+      if (tid == 0) *reinterpret_cast<volatile int*>(smem) = sched_resolve(g.sched, my_list, ticket, ntiles);
       __syncthreads();
+      next_logical = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+      __syncthreads();                // ... and everybody has read it before the staging below overwrites the word
     }
     int lane_e = threadIdx.x & 63, m0e = m0, n0e = n0;
     asm volatile("" : "+v"(lane_e), "+s"(m0e), "+s"(n0e));
-    const int next_logical = dyn ? __builtin_amdgcn_readfirstlane(s_next) : logical + (int)gridDim.x;
     const bool has_next = gridDim.y == 1 && next_logical >= 0 && next_logical < ntiles;
     if (has_next) {   // LDS is idle from here on: the next tile's first two K tiles travel under the epilogue
       set_tile(next_logical);
@@ -312,8 +328,8 @@ template <int LAYOUT, int EPI>
 int launch4w_one(const GemmArgs& a, int nsplit, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<LAYOUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (e != hipSuccess) { crl_set_error("gemm4w: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -2; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<LAYOUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e != hipSuccess) { crl_set_error("gemm4w: cannot enable 160 KiB LDS: %s", hipGetErrorString(e)); return -2; }
     configured = true;
   }
   int grid_x = a.ntm * a.ntn;
@@ -324,7 +340,7 @@ int launch4w_one(const GemmArgs& a, int nsplit, hipStream_t s) {
     grid_x = ncu;
     if (crl_gemm_dynamic()) { bool ok; b.sched = crl_sched_slot(s, &ok); if (!ok) return -2; }
   }
-  gemm4w_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T4W, 131072, s>>>(b);
+  gemm4w_kernel<LAYOUT, EPI><<<dim3(grid_x, nsplit), T4W, 163840, s>>>(b);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(4w)");
   return 0;
 }

@@ -54,6 +54,23 @@ __device__ __forceinline__ void sched_leave(uint32_t* st, uint32_t nwg) {   // o
   }
 }
 
+// ---- position in the (XCD-aware) tile order -> tile coordinates.  Round 5: GROUPED order -- positions fill blocks of TILE_GROUP_M tile rows
+// column by column, so the ~32 consecutive positions the resident workgroups of one XCD hold at any time form an 8 x 4 block of tiles that
+// shares 8 A row panels and 4 B column panels (12 panel fetches per K step into that XCD's L2) instead of a 1 x 32 strip of a row-major order
+// (33 panel fetches when the output is 32 tiles wide: at 8192^3 the operand traffic behind the L2s, not the MFMA loop, set the pace).
+#ifndef TILE_GROUP_M
+#define TILE_GROUP_M 8
+#endif
+__device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {
+  if (TILE_GROUP_M <= 1) { tm = t / ntn; tn = t % ntn; return; }
+  const int per_group = TILE_GROUP_M * ntn;
+  const int grp = t / per_group, r = t - grp * per_group;
+  const int first = grp * TILE_GROUP_M;
+  const int gm = min(ntm - first, TILE_GROUP_M);
+  tm = first + r % gm;
+  tn = r / gm;
+}
+
 // ---- swizzles (see the bank analysis in DESIGN.md "GEMM LDS images") ----
 template <int BK> __device__ __forceinline__ int km_swz(int row) {
   return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);

@@ -8,37 +8,47 @@ and reads ONE A half-tile + ONE B half-tile from LDS: 32 ds_read_b128 per 128 MF
 kernel of gemm256.hip (24 per 64), the lever rule 28 of the guide ranks for a loop that is held down by power, and the structure of the
 vendor kernel that sustains 1.64 PF/s on the box where gemm256 sustains 1.24 (profiles/r5_yardstick.txt).
 
-Registers (hand-allocated; everything above v63 is left to the compiler):
+Registers (hand-allocated: v[0 : N_HAND); everything above is left to the compiler):
   v[0:31]   A fragments A_i (i = 0..7: rows 16 i.. of the wave's quadrant) of the current k-step of 32
   v[32:63]  B fragments B_j (j = 0..7)
+  v[64:..]  the fragment-read base addresses + 64 KiB and + 128 KiB (a ds_read offset has 16 bits, the ring is 160 KiB)
   a[0:255]  accumulators (physical-register asm outputs: the C++ epilogue reads them)
 ONE fragment set: the MFMA order of a k-step is  [i = 0..7] x [j = 0..3]  then  [i = 0..7] x [j = 4..7], so A_i is free after MFMA 35 + 4 i,
 B_j (j < 4) after MFMA 28 + j and B_j (j >= 4) after MFMA 60 + j - 4; each fragment of the NEXT k-step is re-read right behind the last use of
 its register, 22..31 MFMAs (>= 350 cycles) before its first use.
 
-LDS = 2 K-tile buffers x 4 half-tiles of 16 KiB, the images of gemm256.hip (KM: [128 rows][64 k], 16-byte slots XOR-swizzled; TR: [64 k][128
-cols] for k-major operands, read with ds_read_b64_tr_b16), laid out so that the two buffers of a half-tile are 16 KiB apart: unit (slot, buffer)
-at (2 slot + buffer) * 16384 with slot 0 = A rows 0..127, 1 = B cols 0..127, 2 = B cols 128..255, 3 = A rows 128..255 -- every LDS address of
-the loop is a per-lane base register + an immediate.  Staging is LDS-DMA (buffer_load_dwordx4 ... lds), 16 pieces of 1 KiB per wave and K tile.
-
-Synchronisation per K tile t (its second k-step): barrier ALPHA (gap 6: every wave has finished reading the A half-tiles of tile t) -> the 8 A
-pieces of tile t + 2 go into the same buffer; barrier BETA (gap 31: the B half-tiles of tile t are read, tile t + 1 has landed: vmcnt(8) leaves
-only the A pieces just issued in flight) -> the 8 B pieces of tile t + 2.  Every piece has >= 97 MFMAs (~1.5 k cycles) to land.
-K tiles past the end of the contraction arrive as zeros (the descriptors' num_records are zeroed in the stream: s_live counts the tiles left).
+LDS = a ring of FIVE pair-slots of 32 KiB (all 160 KiB): the A pair [rows 0..127 | rows 128..255] and the B pair [cols 0..127 | cols 128..255] of a
+K tile are two consecutive ring units, A(t) in slot 2 t mod 5, B(t) in slot (2 t + 1) mod 5; half-tile images as in gemm256.hip (KM: [128 rows][64
+k], 16-byte slots XOR-swizzled; TR: [64 k][128 cols] for k-major operands, read with ds_read_b64_tr_b16).  The slot pattern repeats every five K
+tiles: the loop is unrolled five-fold so that every LDS address is a per-lane base register + an immediate.  Staging is LDS-DMA
+(buffer_load_dwordx4 ... lds), 16 pieces of 1 KiB per wave and K tile, issued EVENLY over the K tile: measured (profiles/r5_gemm4w_*.txt), a
+burst of pieces from all four waves behind a barrier saturates the CU's address path and stalls the only wave each SIMD has (1.0 PF/s), the
+same 16 pieces spread out cost 18 % of the MFMA-only rate (1.46 vs 1.82 PF/s at 8192^3).  Two K tiles of look-ahead:
+  tile t, k-step 0:  the 8 A pieces of tile t + 2 -> slot of B(t - 1), released at BETA of tile t - 1
+  tile t, k-step 1:  [ALPHA, gap 6: every wave has read A(t)]  the 8 B pieces of tile t + 2 -> slot of A(t);
+                     BETA, gap 31: B(t) is read, tile t + 1 has landed (counted vmcnt: the pieces of tile t + 2 stay in flight) -> reads of tile t + 1
+Every piece has >= 99 MFMAs (~1.7 k cycles) to land, most have 160+.  K tiles past the end of the contraction arrive as zeros (the
+descriptors' num_records are zeroed in the stream: s_live counts the tiles left to stage).
 
 The statement is entered with K tiles 0 and 1 of the output tile staged by the C++ wrapper (it issues them under the previous tile's epilogue)
-and left with every accumulator complete and no memory operation outstanding.
+and left with every accumulator complete, no memory operation outstanding and every wave behind a barrier (the LDS is free).
+Diagnostics: G4W_DROP=class,... (timing-only builds, WRONG results: dsread dma barrier vmwait), G4W_OPTS=alpha=0 (no ALPHA barrier: the B pieces
+follow BETA), scripts/ab_g4w.sh builds such variants into separate libraries.
 """
 import os
 import sys
 
-FA, FB = 0, 32
-N_HAND = 64
+FA, FB, VX = 0, 32, 64
 KINDS = {'nt': ('km', 'km'), 'nn': ('km', 'tr'), 'tn': ('tr', 'tr')}     # (A, B): km = k-contiguous rows, tr = k-major (transposed read)
 SRD = {'A': 36, 'B': 40}          # pinned SGPR tuples s[36:39], s[40:43] (the stream zeroes word 2 = num_records at the end of the contraction)
-ALPHA_GAP, BETA_GAP = 6, 31
 OPTS = dict(kv.split('=') if '=' in kv else (kv, '1') for kv in filter(None, os.environ.get('G4W_OPTS', '').split(',')))
-DROP = set(filter(None, os.environ.get('G4W_DROP', '').split(',')))      # timing-only builds (WRONG results): dsread dma barrier
+DROP = set(filter(None, os.environ.get('G4W_DROP', '').split(',')))
+USE_ALPHA = OPTS.get('alpha', '1') != '0'
+ALPHA_GAP, BETA_GAP = 6, 31
+A_GAPS = [2, 10, 18, 26, 34, 42, 50, 58]                       # k-step 0: the A pieces of tile t + 2
+B_GAPS = [8, 14, 20, 26, 32, 38, 44, 50] if USE_ALPHA else [32, 36, 40, 44, 48, 52, 56, 60]      # k-step 1: the B pieces of tile t + 2
+NB_BEFORE_BETA = sum(1 for g in B_GAPS if g < BETA_GAP)
+RING = 5
 
 
 def op(name):
@@ -69,34 +79,61 @@ def kstep_order():
     return [(i, j) for i in range(8) for j in range(4)] + [(i, j) for i in range(8) for j in range(4, 8)]
 
 
+def slot_of(opnd, t):
+    return (2 * t + (1 if opnd == 'B' else 0)) % RING
+
+
 class Gen:
     def __init__(self, layout):
         self.layout = layout
         self.kind = dict(zip('AB', KINDS[layout]))
+        # base operands handed in by the wrapper (ring offset 0) and their hand-allocated copies at + 64 KiB / + 128 KiB
+        self.bases = []
+        for o in 'AB':
+            self.bases += [f'ar{o}k0', f'ar{o}k1'] if self.kind[o] == 'km' else [f'ar{o}t{j}' for j in range(8)]
+        self.hi = {}
+        r = VX
+        for n in self.bases:
+            self.hi[n] = (r, r + 1)
+            r += 2
+        self.n_hand = r
 
-    # ---- fragment reads
-    def read_frag(self, opnd, idx, ks, b, tag):
+    def addr(self, name, slot):
+        """(register text, immediate part) of ring slot `slot` for base operand `name`"""
+        k = slot >> 1
+        reg = op(name) if k == 0 else f'v{self.hi[name][k - 1]}'
+        return reg, (slot & 1) * 32768
+
+    def entry_code(self):
+        out = []
+        for n in self.bases:
+            out.append(I(f'v_add_u32 v{self.hi[n][0]}, 0x10000, {op(n)}', 'valu'))
+            out.append(I(f'v_add_u32 v{self.hi[n][1]}, 0x20000, {op(n)}', 'valu'))
+        return out
+
+    # ---- fragment reads of K tile t (ring position), k-step ks
+    def read_frag(self, opnd, idx, ks, t, tag):
         base = (FA if opnd == 'A' else FB) + 4 * idx
+        slot = slot_of(opnd, t % RING)
         if self.kind[opnd] == 'km':
-            return [I(f'ds_read_b128 v[{base}:{base + 3}], {op(f"ar{opnd}k{ks}")} offset:{b * 16384 + idx * 2048}', 'ds', writes=vregs(base, 4), tag=tag)]
-        off = b * 16384 + ks * 8192
-        return [I(f'ds_read_b64_tr_b16 v[{base}:{base + 1}], {op(f"ar{opnd}t{idx}")} offset:{off}', 'ds', writes=vregs(base, 2), tag=tag),
-                I(f'ds_read_b64_tr_b16 v[{base + 2}:{base + 3}], {op(f"ar{opnd}t{idx}")} offset:{off + 1024}', 'ds', writes=vregs(base + 2, 2), tag=tag)]
+            reg, imm = self.addr(f'ar{opnd}k{ks}', slot)
+            return [I(f'ds_read_b128 v[{base}:{base + 3}], {reg} offset:{imm + idx * 2048}', 'ds', writes=vregs(base, 4), tag=tag)]
+        reg, imm = self.addr(f'ar{opnd}t{idx}', slot)
+        off = imm + ks * 8192
+        return [I(f'ds_read_b64_tr_b16 v[{base}:{base + 1}], {reg} offset:{off}', 'ds', writes=vregs(base, 2), tag=tag),
+                I(f'ds_read_b64_tr_b16 v[{base + 2}:{base + 3}], {reg} offset:{off + 1024}', 'ds', writes=vregs(base + 2, 2), tag=tag)]
 
     def vops(self):
-        out = []
-        for o in 'AB':
-            out += [f'ar{o}k0', f'ar{o}k1'] if self.kind[o] == 'km' else [f'ar{o}t{j}' for j in range(8)]
-        return out + ['voffA', 'voffB']
+        return self.bases + ['voffA', 'voffB']
 
-    # ---- LDS-DMA pieces of one operand for K tile -> buffer b (slots: A0 = 0, B0 = 1, B1 = 2, A1 = 3)
-    def dma_group(self, opnd, b):
+    # ---- the 8 LDS-DMA pieces of one operand pair of K tile t (ring position): half h at + 16 KiB, piece `it` at + 4 KiB
+    def dma_group(self, opnd, t):
         out = []
-        slots = (0, 3) if opnd == 'A' else (1, 2)
         srd = SRD[opnd]
-        for h, slot in enumerate(slots):
+        slot = slot_of(opnd, t % RING)
+        for h in range(2):
             for it in range(4):
-                m0 = (2 * slot + b) * 16384 + it * 4096
+                m0 = slot * 32768 + h * 16384 + it * 4096
                 piece = [I(f's_add_u32 m0, {op("s_ldsw")}, {m0}', 'salu')]
                 if h == 0 and it == 0:
                     piece.append(I('s_nop 0', 'salu'))
@@ -113,52 +150,47 @@ class Gen:
                 out.append(piece)
         return out
 
-    # ---- one k-step: 64 MFMAs + fillers
-    def kstep(self, b, ks, zero_c, tile_tag):
-        """tile in buffer b, k-step ks.  tag of a read = (tile_tag of the tile it reads, operand)"""
-        bb = [mfma(i, j, zero_c) for (i, j) in kstep_order()]
-        gaps = [[] for _ in range(64)]
-        nb, nks, ntag = (b, 1, tile_tag) if ks == 0 else (1 - b, 0, tile_tag + 1)
-        for jj, j in enumerate(range(4, 8)):                        # B_j (j >= 4) of THIS k-step (their registers were busy until MFMA 60.. of the previous one)
-            gaps[1 + 4 * jj] += self.read_frag('B', j, ks, b, (tile_tag, 'B'))
-        for j in range(4):
-            gaps[33 + 4 * j] += self.read_frag('B', j, nks, nb, (ntag, 'B'))
-        for i in range(8):
-            gaps[35 + 4 * i] += self.read_frag('A', i, nks, nb, (ntag, 'A'))
-        if ks == 1:
-            # ALPHA: the A half-tiles of this tile are read by every wave -> restage them with tile + 2
-            gaps[ALPHA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tile_tag, 'A')]),
-                                I(f's_cmp_gt_i32 {op("s_live")}, 0', 'salu'),
-                                I(f's_cselect_b32 s{SRD["A"] + 2}, s{SRD["A"] + 2}, 0', 'salu'),
-                                I(f's_cselect_b32 s{SRD["B"] + 2}, s{SRD["B"] + 2}, 0', 'salu'),
-                                I(f's_sub_u32 {op("s_live")}, {op("s_live")}, 1', 'salu'),
-                                I('s_barrier', 'barrier')]
-            a_gaps = [7, 10, 13, 16, 19, 22, 25, 28]
-            for g, piece in zip(a_gaps, self.dma_group('A', b)):
-                gaps[g] += piece
-            gaps[a_gaps[-1]] += [I(f's_add_u32 {op("s_offA")}, {op("s_offA")}, {op("s_ktA")}', 'salu')]
-            # BETA: the B half-tiles are read, the next tile has landed (all but the 8 A pieces just issued)
-            gaps[BETA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tile_tag, 'B'), (tile_tag, 'A')], ),
-                               I('s_waitcnt vmcnt(8)', 'vmwait'),
-                               I('s_barrier', 'barrier')]
-            b_gaps = [34, 38, 42, 46, 50, 54, 58, 62]
-            for g, piece in zip(b_gaps, self.dma_group('B', b)):
-                gaps[g] += piece
-            gaps[b_gaps[-1]] += [I(f's_add_u32 {op("s_offB")}, {op("s_offB")}, {op("s_ktB")}', 'salu')]
-        return bb, gaps
-
-    def pair(self, first, tag0):
-        """K tiles (tag0 -> buffer 0, tag0 + 1 -> buffer 1)"""
+    # ---- one K tile = two k-steps of 64 MFMAs + fillers.  t = ring position (tile index mod 5), tag = running tile number (hazard tags)
+    def tile(self, t, tag, first):
         out = []
-        for b in range(2):
-            for ks in range(2):
-                out.append(self.kstep(b, ks, first and b == 0 and ks == 0, tag0 + b))
+        for ks in range(2):
+            bb = [mfma(i, j, first and ks == 0) for (i, j) in kstep_order()]
+            gaps = [[] for _ in range(64)]
+            nt, nks, ntag = (t, 1, tag) if ks == 0 else (t + 1, 0, tag + 1)
+            for jj, j in enumerate(range(4, 8)):                    # B_j (j >= 4) of THIS k-step (their registers were busy until MFMA 60.. of the previous one)
+                gaps[1 + 4 * jj] += self.read_frag('B', j, ks, t, (tag, 'B'))
+            for j in range(4):
+                gaps[33 + 4 * j] += self.read_frag('B', j, nks, nt, (ntag, 'B'))
+            for i in range(8):
+                gaps[35 + 4 * i] += self.read_frag('A', i, nks, nt, (ntag, 'A'))
+            if ks == 0:
+                # the A pair of tile t + 2 -> the slot B(t - 1) left at BETA of the previous tile
+                gaps[A_GAPS[0] - 1] += [I(f's_cmp_gt_i32 {op("s_live")}, 0', 'salu'),
+                                        I(f's_cselect_b32 s{SRD["A"] + 2}, s{SRD["A"] + 2}, 0', 'salu')]
+                for g, piece in zip(A_GAPS, self.dma_group('A', t + 2)):
+                    gaps[g] += piece
+                gaps[A_GAPS[-1]] += [I(f's_add_u32 {op("s_offA")}, {op("s_offA")}, {op("s_ktA")}', 'salu')]
+            else:
+                pre = [I(f's_cmp_gt_i32 {op("s_live")}, 0', 'salu'),
+                       I(f's_cselect_b32 s{SRD["B"] + 2}, s{SRD["B"] + 2}, 0', 'salu'),
+                       I(f's_sub_u32 {op("s_live")}, {op("s_live")}, 1', 'salu')]
+                if USE_ALPHA:
+                    # ALPHA: the A pair of this tile is read by every wave -> the B pair of tile t + 2 goes into its slot
+                    gaps[ALPHA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tag, 'A')])] + pre + [I('s_barrier', 'barrier')]
+                # BETA: the B pair is read too, the next tile has landed (the pieces of tile t + 2 issued so far stay in flight)
+                gaps[BETA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tag, 'B'), (tag, 'A')]),
+                                   I(f's_waitcnt vmcnt({8 + NB_BEFORE_BETA})', 'vmwait')] + ([] if USE_ALPHA else pre) + [I('s_barrier', 'barrier')]
+                for g, piece in zip(B_GAPS, self.dma_group('B', t + 2)):
+                    gaps[g] += piece
+                gaps[B_GAPS[-1]] += [I(f's_add_u32 {op("s_offB")}, {op("s_offB")}, {op("s_ktB")}', 'salu')]
+            out.append((bb, gaps))
         return out
 
 
 class Hazards:
     """linear walk: counted lgkmcnt waits for LDS reads before their consumers (merged: a wait also covers every older-than-OLD read)"""
     OLD = 12      # a read issued >= OLD MFMAs ago has certainly returned: waiting for it costs nothing
+    in_loop = False
 
     def __init__(self):
         self.out = []
@@ -198,11 +230,12 @@ class Hazards:
         if ins.kind == 'mfma':
             self.n_mfma += 1
 
-    in_loop = False
-
     def drain(self, text):
         self.out.append(I(text, 'wait'))
         self.pending = []
+
+    def state(self, shift=0):
+        return [(sorted(w), (t[0] - shift, t[1]), n - self.n_mfma) for (w, t, n) in self.pending]
 
 
 def generate(layout):
@@ -210,6 +243,8 @@ def generate(layout):
     H = Hazards()
     E = H.emit
     # ---- entry: K tiles 0 and 1 were issued by the wrapper; every wave's pieces landed -> barrier -> fragments of (tile 0, k-step 0)
+    for ins in G.entry_code():
+        E(ins)
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
     E(I('s_barrier', 'barrier'))
     for j in range(4):
@@ -219,28 +254,24 @@ def generate(layout):
         for ins in G.read_frag('A', i, 0, 0, (0, 'A')):
             E(ins)
 
-    def emit_pair(first, tag0):
-        for bb, gaps in G.pair(first, tag0):
+    def emit_tile(t, tag, first):
+        for bb, gaps in G.tile(t, tag, first):
             for g, m in enumerate(bb):
                 E(m)
                 for ins in gaps[g]:
                     E(ins)
+        E(I(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1', 'salu'))
+        E(I(f's_cmp_eq_u32 {op("s_cnt")}, 0', 'salu'))
+        E(I('s_cbranch_scc1 EXIT%=', 'branch'))
 
     H.in_loop = True
-    emit_pair(True, 0)
-    E(I(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1', 'salu'))
-    E(I(f's_cmp_eq_u32 {op("s_cnt")}, 0', 'salu'))
-    E(I('s_cbranch_scc1 EXIT%=', 'branch'))
-    # the loop body starts from the same pending-read state as the code behind the first pair (tags are relative: shift by 2 per pair)
-    state = [(w, (t[0] - 2, t[1]), n - H.n_mfma) for (w, t, n) in H.pending]
-    H.out.append(I('LOOP%=:', 'label'))
-    H.pending = [(w, t, n + H.n_mfma) for (w, t, n) in state]
-    emit_pair(False, 0)
-    end_state = [(w, (t[0] - 2, t[1]), n - H.n_mfma) for (w, t, n) in H.pending]
-    assert [(sorted(w), t) for (w, t, n) in end_state] == [(sorted(w), t) for (w, t, n) in state], 'loop-carried LDS state differs'
-    E(I(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1', 'salu'))
-    E(I(f's_cmp_eq_u32 {op("s_cnt")}, 0', 'salu'))
-    E(I('s_cbranch_scc0 LOOP%=', 'branch'))
+    emit_tile(0, 0, True)                 # the first K tile of an output tile starts the accumulators (C = 0)
+    s1 = H.state(0)
+    H.out.append(I('LOOP%=:', 'label'))   # memory order of the loop body: ring positions 1, 2, 3, 4, 0
+    for t in range(1, 6):
+        emit_tile(t % RING, t, False)
+    assert H.state(RING) == s1, 'loop-carried LDS state differs'
+    E(I('s_branch LOOP%=', 'branch'))
     H.in_loop = False
     H.out.append(I('EXIT%=:', 'label'))
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
@@ -260,17 +291,22 @@ def render(stream, G):
         ', '.join(f'[{n}] "+&s"({n})' for n in srw) + ', [s_t] "=&s"(s_t)'
     sin = ['s_ldsw', 's_itA', 's_halfA', 's_ktA', 's_itB', 's_halfB', 's_ktB']
     ins_ = ', '.join(f'[{n}] "v"({n})' for n in G.vops()) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
-    clob = ', '.join(f'"v{i}"' for i in range(N_HAND)) + ', "vcc", "scc", "memory"'
+    clob = ', '.join(f'"v{i}"' for i in range(G.n_hand)) + ', "vcc", "scc", "memory"'
     return (f'// GENERATED by gen_gemm4w.py ({G.layout}) -- do not edit; see that file for the register map and the schedule\n'
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
 
 
-if __name__ == '__main__':
-    here = os.path.dirname(os.path.abspath(__file__))
+def generate_all(outdir):
     for layout in KINDS:
         stream, G = generate(layout)
-        with open(os.path.join(here, f'gemm4w_body_{layout}.inc'), 'w') as f:
+        with open(os.path.join(outdir, f'gemm4w_body_{layout}.inc'), 'w') as f:
             f.write(render(stream, G))
+        yield layout, stream
+
+
+if __name__ == '__main__':
+    here = os.path.dirname(os.path.abspath(__file__))
+    for layout, stream in generate_all(here):
         if '-v' in sys.argv:
             kinds = {}
             for ins in stream:

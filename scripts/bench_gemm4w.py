@@ -51,11 +51,20 @@ def case(name, layout, M, N, K, epi=ops.EPI_BF16, vendor=False, policy=0, rounds
             ms = timed(fv, n)
             row.append(f'vendor {ms * 1000:8.1f} us {flops / ms / 1e9:7.1f} TF/s')
         print(f'{name:26s} {layout} {M}x{N}x{K} epi {epi} pol {policy} | ' + ' | '.join(row), flush=True)
-    hip.call('crl_gemm_set_policy', 0); hip.call('crl_gemm_set_big_kernel', 1)
+    hip.call('crl_gemm_set_policy', 0); hip.call('crl_gemm_set_big_kernel', 2)
 
 
 if __name__ == '__main__':
     M = 49512
+    if len(sys.argv) > 1 and sys.argv[1] == 'k1024':    # the epilogue-heavy K = 1024 launches of an encoder block (+ the two residual ones)
+        tag = os.path.basename(os.environ.get('PIXPARSE_AMD_LIB', 'default'))
+        case(f'{tag} qkv', 'NT', M, 3072, 1024, rounds=1)
+        case(f'{tag} proj resid', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, rounds=1)
+        case(f'{tag} fc1 gelu', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU, rounds=1)
+        case(f'{tag} fc2 resid', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, rounds=1)
+        case(f'{tag} dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, rounds=1)
+        case(f'{tag} dgrad proj', 'NN', M, 1024, 1024, rounds=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'one':      # variant runs (scripts/ab_g4w.sh): the main-loop-bound case + one K = 1024 case
         tag = os.path.basename(os.environ.get('PIXPARSE_AMD_LIB', 'default'))
         case(f'{tag} square 8192', 'NT', 8192, 8192, 8192, policy=2)

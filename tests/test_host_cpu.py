@@ -61,6 +61,45 @@ def test_swin_window_attention_is_compiled_to_mfma():
     assert 'ds_read_b64_tr_b16' in fwd and 'ds_read_b64_tr_b16' in bwd
 
 
+def test_gemm4w_streams_are_in_sync_and_counted():
+    """csrc/gemm4w_body_{nt,nn,tn}.inc (the hand-placed main loops of the one-wave-per-SIMD GEMM, committed) are exactly what csrc/gen_gemm4w.py
+    generates today; per K tile a wave issues the 128 MFMAs, the 32 fragment reads (64 half-reads for a k-major operand), the 16 LDS-DMA pieces and
+    the two barriers the design counts; every LDS read is covered by a counted wait before its first consumer (the generator's own walk)."""
+    import importlib.util, re
+    from pixparse_amd import build as b
+    spec = importlib.util.spec_from_file_location('gen_gemm4w', os.path.join(b.CSRC, 'gen_gemm4w.py'))
+    gen = importlib.util.module_from_spec(spec)
+    for k in ('G4W_DROP', 'G4W_OPTS'):
+        assert not os.environ.get(k), f'{k} is set: the committed streams are the default build'
+    spec.loader.exec_module(gen)
+    for layout, (ka, kb) in gen.KINDS.items():
+        stream, G = gen.generate(layout)
+        text = gen.render(stream, G)
+        assert text == open(os.path.join(b.CSRC, f'gemm4w_body_{layout}.inc')).read(), f'gemm4w_body_{layout}.inc is stale: run python pixparse_amd/csrc/gen_gemm4w.py'
+        body = text[text.index('LOOP%=:'):text.index('EXIT%=:')]            # five K tiles (ring positions 1, 2, 3, 4, 0)
+        assert body.count('v_mfma_f32_16x16x32_bf16') == 5 * 128 and body.count('s_barrier') == 5 * 2
+        assert body.count('offen lds') == 5 * 16
+        n_km = (ka == 'km') + (kb == 'km')
+        assert body.count('ds_read_b128') == 5 * 16 * n_km and body.count('ds_read_b64_tr_b16') == 5 * 32 * (2 - n_km)
+        assert len(re.findall(r'v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], 0\\n', text)) == 64     # the first k-step of an output tile starts the 64 accumulator tiles from C = 0
+        assert not re.search(r'scratch_|v_accvgpr', text)
+        # replay the stream: no MFMA may read a fragment register with an LDS read still pending (lgkmcnt is in-order)
+        pending = []
+        for ins in stream:
+            if ins.kind == 'wait' and 'lgkmcnt' in ins.text:
+                n = int(re.search(r'lgkmcnt\((\d+)\)', ins.text).group(1))
+                pending = pending[len(pending) - n:] if n < len(pending) else pending
+                if n == 0:
+                    pending = []
+            elif ins.kind == 'ds':
+                pending.append(ins.writes)
+            elif ins.kind == 'mfma':
+                busy = set().union(*pending) if pending else set()
+                assert not (busy & ins.reads), f'{layout}: {ins.text} reads a fragment that is still being loaded'
+            elif ins.kind == 'label':
+                pending = list(pending)
+
+
 def test_attention_backward_stream_is_in_sync_and_its_hazard_pass_bites():
     """csrc/attn_bwd_sp_body.inc (the hand-placed single-pass attention backward, committed) is exactly what csrc/gen_attn_bwd_sp.py
     generates today; per 64-query tile pass it holds the 80 MFMAs the design counts, and the generator's hazard pass refuses a schedule

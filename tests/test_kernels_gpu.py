@@ -377,7 +377,7 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy, big):
         close(dw, 3.0 + dy.float().t() @ x.float(), 2e-3, 5e-2, '256 TN acc')
     finally:
         hip.call('crl_gemm_set_policy', 0)
-        hip.call('crl_gemm_set_big_kernel', 1)
+        hip.call('crl_gemm_set_big_kernel', 2)
 
 
 @pytest.mark.parametrize('M,N,K', [(600, 520, 192), (256 * 9 + 40, 1024, 1024), (1024, 768, 64), (4096, 4096, 4096 + 64)])
@@ -423,7 +423,7 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
         again = run()
     finally:
         hip.call('crl_gemm_set_policy', 0)
-        hip.call('crl_gemm_set_big_kernel', 1)
+        hip.call('crl_gemm_set_big_kernel', 2)
     ref = x.float() @ w.float().t() + bias.to(BF16).float()
     ref[:, :min(N, 256)] *= 0.25
     close(got[0], ref, 1e-2, 1e-2, '4w NT vs fp32')
