@@ -59,6 +59,9 @@ int crl_gemm_set_policy(int policy);
  * (gemm4w.hip, round 5) where a workgroup walks >= 32 K tiles behind a store-only epilogue (weight gradients, long-K dgrads), else the 8-wave
  * 8-phase kernel (gemm256.hip); 1 / 0 force one of them.  Same results bit for bit; tests / same-box A-B.  Process-wide. */
 int crl_gemm_set_big_kernel(int which);
+/* 1 (default): plain-bf16 NT / NN launches of the 4-wave kernel whose columns are whole tiles run the epilogue of output tile T inside the main loop
+ * of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles.  Same results bit for bit.  Process-wide. */
+int crl_gemm_set_overlap(int on);
 /* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
    < 0 = never cut.  Process-wide. */
 int crl_gemm_set_quant_cost(float c);

@@ -222,6 +222,7 @@ int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
 
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
 int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
+bool crl_gemm4w_overlaps(int layout, int epi, const gemmc::GemmArgs& a, int nsplit);   // the 4-wave kernel would run this launch with the epilogue of tile T inside the main loop of tile T + 1
 int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t s);
 
 // ---- launch geometry of the persistent kernels + the ticket-counter pool of the dynamic tile scheduler (gemm_common.h) ----
@@ -283,7 +284,7 @@ static int g_big4w = G_BIG_4W;
 static int big_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
   const bool store_only = epi == CRL_EPI_BF16 || epi == CRL_EPI_F32 || epi == CRL_EPI_F32_ACC;
   const int nk_wg = nsplit > 1 ? a.kchunk : (a.K + 63) / 64;
-  const bool four = g_big4w == 1 || (g_big4w == 2 && store_only && nk_wg >= 32);
+  const bool four = g_big4w == 1 || (g_big4w == 2 && ((store_only && nk_wg >= 32) || crl_gemm4w_overlaps(layout, epi, a, nsplit)));
   return four ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
 }
 extern "C" int crl_gemm_set_big_kernel(int which) {

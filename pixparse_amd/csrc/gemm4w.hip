@@ -324,6 +324,158 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
   if (dyn && tid == 0) sched_leave(g.sched, gridDim.x);
 }
 
+// ---- the OVERLAPPED form (plain bf16 epilogue: bias, column scale, bf16 rounding; NT / NN): the epilogue of output tile T runs inside the
+// statement of tile T + 1 -- its accumulators are packed to bf16 (128 registers) at the statement's entry while the staging DMA of T + 1's
+// first two K tiles is in flight, and its 32 stores per lane are spread over T + 1's first five K tiles (gen_gemm4w.py): no workgroup ever
+// sits in an epilogue with its matrix pipes idle and the tile-sized store traffic of the 256 CUs no longer arrives in one burst.  The last
+// tile of a workgroup is finished by a drain statement.  Same arithmetic as epilogue4w / gemm_epilogue.h (bit-identical results); the
+// accumulators are carried from statement to statement as in-out physical-register operands (the compiler leaves them in place).
+template <int LAYOUT>
+__global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool B_TR = (LAYOUT != CRL_NT);
+  static_assert(LAYOUT != CRL_TN, "weight gradients have fp32 outputs: classic form");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntiles = g.ntm * g.ntn;
+  const bool dyn = g.sched != nullptr;
+  uint32_t ticket = 0;
+  int my_list = 0;
+  int logical = blockIdx.x;
+  if (dyn) {
+    if (tid == 0) {
+      my_list = sched_xcd();
+      ticket = sched_pull(g.sched + my_list);
+      *reinterpret_cast<volatile int*>(smem) = sched_resolve(g.sched, my_list, ticket, ntiles);
+    }
+    __syncthreads();
+    logical = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+    __syncthreads();
+    if (logical < 0) {
+      if (tid == 0) sched_leave(g.sched, gridDim.x);
+      return;
+    }
+  }
+  int m0, n0;
+  auto set_tile = [&](int l) {
+    const int t = xcd_remap(l, ntiles);
+    int tm, tn;
+    tile_coords(t, g.ntm, g.ntn, tm, tn);
+    m0 = tm * 256;
+    n0 = tn * 256;
+  };
+  set_tile(logical);
+
+  const u32x4 ra = make_srd(g.A, g.a_bytes);
+  const u32x4 rb = make_srd(g.B, g.b_bytes);
+  const uint32_t smem_base = lds_addr_of(smem);
+  const int nk = (g.K + 63) / 64;
+  const uint32_t s_ldsw = smem_base + (uint32_t)wave * 1024u;
+  const uint32_t s_itA = 32u * g.lda * 2u, s_halfA = 128u * g.lda * 2u, s_ktA = 128u;
+  const uint32_t s_itB = B_TR ? 16u * g.ldb * 2u : 32u * g.ldb * 2u, s_halfB = B_TR ? 256u : 128u * g.ldb * 2u, s_ktB = B_TR ? 64u * g.ldb * 2u : 128u;
+  // epilogue constants
+  const uint32_t nrecC = (uint32_t)(((size_t)(g.M - 1) * (uint32_t)g.ldc + (uint32_t)g.N) * 2u);
+  const u32x4 rc_live = make_srd(g.C, nrecC), rc_dead = make_srd(g.C, 0);       // no previous tile: every store falls off a descriptor without records
+  const u32x4 srdBias = make_srd(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
+  const uint32_t s_cstep = 16u * (uint32_t)g.ldc * 2u, s_cscols = (uint32_t)g.colscale_cols, s_cscale = __float_as_uint(g.colscale);
+
+  f32x4 c[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool have_prev = false;
+  int pm0 = 0, pn0 = 0;
+  for (;;) {   // output tiles of this workgroup
+    if (dyn && tid == 0) ticket = sched_pull(g.sched + my_list);
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int lane = t2 & 63, li = lane & 15, lq = lane >> 4;
+    uint32_t voffA, voffB;
+    { const int r = t2 >> 3; voffA = (uint32_t)r * g.lda * 2u + (uint32_t)(((t2 & 7) ^ km_swz<64>(r)) * 16); }
+    if constexpr (B_TR) { const int kr = t2 >> 4; voffB = (uint32_t)kr * g.ldb * 2u + (uint32_t)(((t2 & 15) ^ tr_swz(kr)) * 16); }
+    else { const int r = t2 >> 3; voffB = (uint32_t)r * g.ldb * 2u + (uint32_t)(((t2 & 7) ^ km_swz<64>(r)) * 16); }
+    const uint32_t unitA = smem_base + (uint32_t)wr * 16384u, unitB = smem_base + (uint32_t)wc * 16384u;
+    const uint32_t km_k0 = (uint32_t)(li * 128 + (((0 + lq) ^ ((li >> 1) & 7)) << 4)), km_k1 = (uint32_t)(li * 128 + (((4 + lq) ^ ((li >> 1) & 7)) << 4));
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tsw = tr_swz(8 * tg + tq);
+    auto tr_addr = [&](int j) { return (uint32_t)((8 * tg + tq) * 256 + ((((2 * j) ^ tsw) + (tp >> 1)) << 4) + 8 * (tp & 1)); };
+    // the previous tile's epilogue: lane (li, lq) stores row 128 wr + 16 i + li, the 8 columns 128 wc + 32 pr + 8 bitswap(lq) .. of every strip pair
+    const uint32_t voffC = (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
+    const uint32_t colv = (uint32_t)(pn0 + 128 * wc + 4 * lq), voffBias = colv * 4u;
+    const u32x4 srdC = have_prev ? rc_live : rc_dead;
+    uint32_t s_crow = ((uint32_t)pm0 * (uint32_t)g.ldc + (uint32_t)pn0) * 2u;
+    u32x4 srdA = ra, srdB = rb;
+    uint32_t s_offA = ((uint32_t)m0 * g.lda) * 2u, s_offB = B_TR ? (uint32_t)n0 * 2u : ((uint32_t)n0 * g.ldb) * 2u;
+    uint32_t s_live = (uint32_t)nk, s_cnt = (uint32_t)nk, s_t;
+    if constexpr (LAYOUT == CRL_NT) {
+      uint32_t arAk0 = unitA + km_k0, arAk1 = unitA + km_k1, arBk0 = unitB + km_k0, arBk1 = unitB + km_k1;
+#include "gemm4w_body_nt_ovl.inc"
+    } else {
+      uint32_t arAk0 = unitA + km_k0, arAk1 = unitA + km_k1;
+      uint32_t arBt0 = unitB + tr_addr(0), arBt1 = unitB + tr_addr(1), arBt2 = unitB + tr_addr(2), arBt3 = unitB + tr_addr(3),
+               arBt4 = unitB + tr_addr(4), arBt5 = unitB + tr_addr(5), arBt6 = unitB + tr_addr(6), arBt7 = unitB + tr_addr(7);
+#include "gemm4w_body_nn_ovl.inc"
+    }
+    have_prev = true;
+    pm0 = m0; pn0 = n0;
+    int next_logical = logical + (int)gridDim.x;
+    if (dyn) {
+      if (tid == 0) *reinterpret_cast<volatile int*>(smem) = sched_resolve(g.sched, my_list, ticket, ntiles);
+      __syncthreads();
+      next_logical = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+      __syncthreads();
+    }
+    if (!(next_logical >= 0 && next_logical < ntiles)) break;
+    logical = next_logical;
+    set_tile(logical);
+  }
+  {   // the last tile of this workgroup: read-out + 32 stores, back to back
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int lane = t2 & 63, li = lane & 15, lq = lane >> 4;
+    const uint32_t voffC = (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
+    const uint32_t colv = (uint32_t)(pn0 + 128 * wc + 4 * lq), voffBias = colv * 4u;
+    const u32x4 srdC = rc_live;
+    uint32_t s_crow = ((uint32_t)pm0 * (uint32_t)g.ldc + (uint32_t)pn0) * 2u;
+#include "gemm4w_drain_ovl.inc"
+  }
+  if (dyn && tid == 0) sched_leave(g.sched, gridDim.x);
+}
+
+// the overlapped form needs whole column tiles (its stores are not column-masked), a contraction long enough to hold the 32 stores of the
+// previous tile (five peeled K tiles) and the plain bf16 epilogue
+#ifndef G4_OVERLAP
+#define G4_OVERLAP 1
+#endif
+static int g4_overlap = G4_OVERLAP;
+bool crl_gemm4w_can_overlap(int layout, int epi, const GemmArgs& a, int nsplit) {
+  return g4_overlap && epi == CRL_EPI_BF16 && layout != CRL_TN && nsplit == 1 && (a.N % 256) == 0 && (a.K % 64) == 0 && a.K / 64 >= 8 && (a.ldc % 8) == 0;
+}
+
+template <int LAYOUT>
+int launch4w_ovl(const GemmArgs& a, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_ovl_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e != hipSuccess) { crl_set_error("gemm4w: cannot enable 160 KiB LDS: %s", hipGetErrorString(e)); return -2; }
+    configured = true;
+  }
+  int grid_x = a.ntm * a.ntn;
+  GemmArgs b = a;
+  b.sched = nullptr;
+  const int ncu = crl_gemm_cus();
+  if (grid_x > ncu) {
+    grid_x = ncu;
+    if (crl_gemm_dynamic()) { bool ok; b.sched = crl_sched_slot(s, &ok); if (!ok) return -2; }
+  }
+  gemm4w_ovl_kernel<LAYOUT><<<dim3(grid_x, 1), T4W, 163840, s>>>(b);
+  CRL_LAUNCH_CHECK("crl_gemm_bf16(4w, overlapped epilogue)");
+  return 0;
+}
+
 template <int LAYOUT, int EPI>
 int launch4w_one(const GemmArgs& a, int nsplit, hipStream_t s) {
   static bool configured = false;
@@ -362,7 +514,10 @@ int launch4w_epi(const GemmArgs& a, int epi, int nsplit, hipStream_t s) {
 }  // namespace
 
 // called by crl_gemm_bf16 (gemm.hip): same contract as crl_gemm256_launch
+extern "C" int crl_gemm_set_overlap(int on) { g4_overlap = on ? 1 : 0; return 0; }
+bool crl_gemm4w_overlaps(int layout, int epi, const gemmc::GemmArgs& a, int nsplit) { return crl_gemm4w_can_overlap(layout, epi, a, nsplit); }
 int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
+  if (crl_gemm4w_can_overlap(layout, epi, a, nsplit)) return layout == CRL_NT ? launch4w_ovl<CRL_NT>(a, s) : launch4w_ovl<CRL_NN>(a, s);
   switch (layout) {
     case CRL_NT: return launch4w_epi<CRL_NT>(a, epi, nsplit, s);
     case CRL_NN: return launch4w_epi<CRL_NN>(a, epi, nsplit, s);

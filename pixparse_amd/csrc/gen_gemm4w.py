@@ -84,8 +84,9 @@ def slot_of(opnd, t):
 
 
 class Gen:
-    def __init__(self, layout):
+    def __init__(self, layout, ovl=False):
         self.layout = layout
+        self.ovl = ovl
         self.kind = dict(zip('AB', KINDS[layout]))
         # base operands handed in by the wrapper (ring offset 0) and their hand-allocated copies at + 64 KiB / + 128 KiB
         self.bases = []
@@ -96,7 +97,9 @@ class Gen:
         for n in self.bases:
             self.hi[n] = (r, r + 1)
             r += 2
-        self.n_hand = r
+        # overlapped epilogue: the previous output tile's results, packed to bf16 -- tile (i, j) = 2 registers at P + 2 (8 i + j)
+        self.P = (r + 3) & ~3
+        self.n_hand = self.P + 128 if ovl else r
 
     def addr(self, name, slot):
         """(register text, immediate part) of ring slot `slot` for base operand `name`"""
@@ -124,10 +127,50 @@ class Gen:
                 I(f'ds_read_b64_tr_b16 v[{base + 2}:{base + 3}], {reg} offset:{off + 1024}', 'ds', writes=vregs(base + 2, 2), tag=tag)]
 
     def vops(self):
-        return self.bases + ['voffA', 'voffB']
+        return self.bases + ['voffA', 'voffB'] + (['voffBias', 'voffC', 'colv'] if self.ovl else [])
+
+    # ---- overlapped epilogue of the PREVIOUS output tile (plain bf16: bias, column scale, bf16 rounding; gemm_epilogue.h operation for operation)
+    def readout(self):
+        """serial, at statement entry, while the staging DMA of this tile's first two K tiles is in flight: the lane's 32 bias values (rounded to
+        bf16 like autocast) into v[0:31], its 8 column scales into v[32 + 2 j], then accumulators -> + bias -> x scale -> bf16 pairs in P"""
+        out = []
+        for j in range(8):
+            out.append(I(f'buffer_load_dwordx4 v[{4 * j}:{4 * j + 3}], {op("voffBias")}, {op("srdBias")}, 0 offen offset:{64 * j}', 'vmem', tag='bias'))
+        return out
+
+    def readout_math(self):
+        out = [I(f'v_mov_b32 v56, {op("s_cscale")}', 'valu')]
+        for j in range(8):
+            out += [I(f'v_add_u32 v57, {16 * j}, {op("colv")}', 'valu'), I(f'v_cmp_gt_u32 vcc, {op("s_cscols")}, v57', 'valu'),
+                    I(f'v_cndmask_b32 v{32 + 2 * j}, 1.0, v56, vcc', 'valu')]
+        for q in range(32):      # round_bf(bias)
+            out += [I(f'v_cvt_pk_bf16_f32 v57, v{q}, v{q}', 'valu'), I(f'v_lshlrev_b32 v{q}, 16, v57', 'valu')]
+        for i in range(8):
+            for j in range(8):
+                n = 8 * i + j
+                t = 48 + 4 * (n & 1)
+                a = acc(i, j)
+                out += [I(f'v_accvgpr_read_b32 v{t + r}, a{a + r}', 'valu') for r in range(4)]
+                out += [I(f'v_pk_add_f32 v[{t}:{t + 1}], v[{t}:{t + 1}], v[{4 * j}:{4 * j + 1}]', 'valu'),
+                        I(f'v_pk_add_f32 v[{t + 2}:{t + 3}], v[{t + 2}:{t + 3}], v[{4 * j + 2}:{4 * j + 3}]', 'valu'),
+                        I(f'v_pk_mul_f32 v[{t}:{t + 1}], v[{t}:{t + 1}], v[{32 + 2 * j}:{33 + 2 * j}] op_sel_hi:[1,0]', 'valu'),
+                        I(f'v_pk_mul_f32 v[{t + 2}:{t + 3}], v[{t + 2}:{t + 3}], v[{32 + 2 * j}:{33 + 2 * j}] op_sel_hi:[1,0]', 'valu'),
+                        I(f'v_cvt_pk_bf16_f32 v{self.P + 2 * n}, v{t}, v{t + 1}', 'valu'),
+                        I(f'v_cvt_pk_bf16_f32 v{self.P + 2 * n + 1}, v{t + 2}, v{t + 3}', 'valu')]
+        return out
+
+    def store_unit(self, u):
+        """row group i = u >> 2, strip pair pr = u & 3: the two 16-column strips of the pair exchange their odd / even 16-lane rows
+        (swap_strips of gemm_epilogue.h) so that a lane owns 8 consecutive columns -> one 16-byte store"""
+        r = self.P + 4 * u
+        out = [I(f'v_permlane16_swap_b32 v{r}, v{r + 2}', 'valu'), I(f'v_permlane16_swap_b32 v{r + 1}, v{r + 3}', 'valu'),
+               I(f'buffer_store_dwordx4 v[{r}:{r + 3}], {op("voffC")}, {op("srdC")}, {op("s_crow")} offen offset:{64 * (u & 3)}', 'vmem', tag='store')]
+        if (u & 3) == 3:
+            out.append(I(f's_add_u32 {op("s_crow")}, {op("s_crow")}, {op("s_cstep")}', 'salu'))
+        return out
 
     # ---- the 8 LDS-DMA pieces of one operand pair of K tile t (ring position): half h at + 16 KiB, piece `it` at + 4 KiB
-    def dma_group(self, opnd, t):
+    def dma_group(self, opnd, t, vtag=None):
         out = []
         srd = SRD[opnd]
         slot = slot_of(opnd, t % RING)
@@ -146,12 +189,13 @@ class Gen:
                     else:
                         piece.append(I(f's_add_u32 {op("s_t")}, {op("s_t")}, {op(f"s_it{opnd}")}', 'salu'))
                     soff = op('s_t')
-                piece.append(I(f'buffer_load_dwordx4 {op(f"voff{opnd}")}, s[{srd}:{srd + 3}], {soff} offen lds', 'dma'))
+                piece.append(I(f'buffer_load_dwordx4 {op(f"voff{opnd}")}, s[{srd}:{srd + 3}], {soff} offen lds', 'dma', tag=vtag))
                 out.append(piece)
         return out
 
     # ---- one K tile = two k-steps of 64 MFMAs + fillers.  t = ring position (tile index mod 5), tag = running tile number (hazard tags)
-    def tile(self, t, tag, first):
+    def tile(self, t, tag, first, fillers=None):
+        """fillers: {(ks, gap): [instructions]} -- the overlapped epilogue pieces placed in this tile"""
         out = []
         for ks in range(2):
             bb = [mfma(i, j, first and ks == 0) for (i, j) in kstep_order()]
@@ -167,7 +211,7 @@ class Gen:
                 # the A pair of tile t + 2 -> the slot B(t - 1) left at BETA of the previous tile
                 gaps[A_GAPS[0] - 1] += [I(f's_cmp_gt_i32 {op("s_live")}, 0', 'salu'),
                                         I(f's_cselect_b32 s{SRD["A"] + 2}, s{SRD["A"] + 2}, 0', 'salu')]
-                for g, piece in zip(A_GAPS, self.dma_group('A', t + 2)):
+                for g, piece in zip(A_GAPS, self.dma_group('A', t + 2, tag + 2)):
                     gaps[g] += piece
                 gaps[A_GAPS[-1]] += [I(f's_add_u32 {op("s_offA")}, {op("s_offA")}, {op("s_ktA")}', 'salu')]
             else:
@@ -179,10 +223,13 @@ class Gen:
                     gaps[ALPHA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tag, 'A')])] + pre + [I('s_barrier', 'barrier')]
                 # BETA: the B pair is read too, the next tile has landed (the pieces of tile t + 2 issued so far stay in flight)
                 gaps[BETA_GAP] += [I('WAIT_TAG', 'waittag', tag=[(tag, 'B'), (tag, 'A')]),
-                                   I(f's_waitcnt vmcnt({8 + NB_BEFORE_BETA})', 'vmwait')] + ([] if USE_ALPHA else pre) + [I('s_barrier', 'barrier')]
-                for g, piece in zip(B_GAPS, self.dma_group('B', t + 2)):
+                                   I(f's_waitcnt vmcnt({8 + NB_BEFORE_BETA})', 'vmwait', tag=tag + 1)] + ([] if USE_ALPHA else pre) + [I('s_barrier', 'barrier')]
+                for g, piece in zip(B_GAPS, self.dma_group('B', t + 2, tag + 2)):
                     gaps[g] += piece
                 gaps[B_GAPS[-1]] += [I(f's_add_u32 {op("s_offB")}, {op("s_offB")}, {op("s_ktB")}', 'salu')]
+            for (fks, g), inss in (fillers or {}).items():
+                if fks == ks:
+                    gaps[g] += inss
             out.append((bb, gaps))
         return out
 
@@ -196,6 +243,8 @@ class Hazards:
         self.out = []
         self.pending = []      # (writes, tag, mfma index at issue)
         self.n_mfma = 0
+        self.vmq = []          # tags of the vector-memory operations issued since the last full drain, in issue order (vmcnt retires in order)
+        self.exact_vm = False  # peeled code: compute counted vmcnt waits from the queue; loop body: the steady-state constant
 
     def _wait_for(self, k):
         """wait until pending[0..k] have returned; extend k over reads that are old anyway"""
@@ -217,6 +266,18 @@ class Hazards:
             if need is not None:
                 self._wait_for(need)
             return
+        if ins.kind == 'vmwait' and self.exact_vm:
+            # all but the operations issued after the last one tagged ins.tag may stay in flight (stores of the overlapped epilogue included)
+            idx = [k for k, t in enumerate(self.vmq) if t == ins.tag]
+            if not idx:
+                return
+            n = len(self.vmq) - 1 - idx[-1]
+            assert n <= 63
+            self.out.append(I(f's_waitcnt vmcnt({n})', 'vmwait'))
+            self.vmq = self.vmq[len(self.vmq) - n:] if n else []
+            return
+        if ins.kind in ('dma', 'vmem'):
+            self.vmq.append(ins.tag)
         used = ins.reads | ins.writes
         need = None
         for k, (wr, tag, _) in enumerate(self.pending):
@@ -233,18 +294,37 @@ class Hazards:
     def drain(self, text):
         self.out.append(I(text, 'wait'))
         self.pending = []
+        if 'vmcnt(0)' in text:
+            self.vmq = []
 
     def state(self, shift=0):
         return [(sorted(w), (t[0] - shift, t[1]), n - self.n_mfma) for (w, t, n) in self.pending]
 
 
-def generate(layout):
-    G = Gen(layout)
+def generate(layout, ovl=False):
+    G = Gen(layout, ovl)
     H = Hazards()
     E = H.emit
-    # ---- entry: K tiles 0 and 1 were issued by the wrapper; every wave's pieces landed -> barrier -> fragments of (tile 0, k-step 0)
     for ins in G.entry_code():
         E(ins)
+    if ovl:
+        # ---- entry of the overlapped form: the LDS is free (the previous statement ended behind a barrier) -> this tile's K tiles 0 and 1 are
+        # staged HERE, behind the bias loads, and the previous tile's accumulators are packed to bf16 while they travel
+        for ins in G.readout():
+            E(ins)
+        for tile in range(2):
+            for opnd in 'AB':
+                E(I(f's_cmp_gt_i32 {op("s_live")}, 0', 'salu'))
+                E(I(f's_cselect_b32 s{SRD[opnd] + 2}, s{SRD[opnd] + 2}, 0', 'salu'))
+                for piece in G.dma_group(opnd, tile, tile):
+                    for ins in piece:
+                        E(ins)
+                E(I(f's_add_u32 {op(f"s_off{opnd}")}, {op(f"s_off{opnd}")}, {op(f"s_kt{opnd}")}', 'salu'))
+            E(I(f's_sub_u32 {op("s_live")}, {op("s_live")}, 1', 'salu'))
+        H.out.append(I('s_waitcnt vmcnt(32)', 'wait'))        # the 8 bias loads (oldest) have landed, the 32 staging pieces stay in flight
+        for ins in G.readout_math():
+            E(ins)
+    # ---- K tiles 0 and 1 have landed for every wave -> barrier -> fragments of (tile 0, k-step 0)
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
     E(I('s_barrier', 'barrier'))
     for j in range(4):
@@ -254,8 +334,8 @@ def generate(layout):
         for ins in G.read_frag('A', i, 0, 0, (0, 'A')):
             E(ins)
 
-    def emit_tile(t, tag, first):
-        for bb, gaps in G.tile(t, tag, first):
+    def emit_tile(t, tag, first, fillers=None):
+        for bb, gaps in G.tile(t, tag, first, fillers):
             for g, m in enumerate(bb):
                 E(m)
                 for ins in gaps[g]:
@@ -265,19 +345,50 @@ def generate(layout):
         E(I('s_cbranch_scc1 EXIT%=', 'branch'))
 
     H.in_loop = True
-    emit_tile(0, 0, True)                 # the first K tile of an output tile starts the accumulators (C = 0)
+    H.exact_vm = True
+    if ovl:
+        # the first FIVE K tiles (one period of the ring) are peeled: they carry the previous tile's 32 stores (two lane exchanges + one 16-byte
+        # store each), one every 18 MFMAs.  The wrapper takes this form only for contractions of >= OVL_MIN_NK K tiles.
+        fill = {}
+        for u in range(32):
+            g = 24 + 18 * u
+            fill.setdefault(g // 128, {}).setdefault(((g % 128) // 64, g % 64), []).extend(G.store_unit(u))
+        for t in range(5):
+            emit_tile(t, t, t == 0, fill.get(t))
+        first_loop = 5
+    else:
+        emit_tile(0, 0, True)                 # the first K tile of an output tile starts the accumulators (C = 0)
+        first_loop = 1
+    H.exact_vm = False
     s1 = H.state(0)
-    H.out.append(I('LOOP%=:', 'label'))   # memory order of the loop body: ring positions 1, 2, 3, 4, 0
-    for t in range(1, 6):
+    H.out.append(I('LOOP%=:', 'label'))   # memory order of the loop body: ring positions 1, 2, 3, 4, 0 (0 .. 4 behind the peeled period)
+    for t in range(first_loop, first_loop + 5):
         emit_tile(t % RING, t, False)
     assert H.state(RING) == s1, 'loop-carried LDS state differs'
     E(I('s_branch LOOP%=', 'branch'))
     H.in_loop = False
     H.out.append(I('EXIT%=:', 'label'))
     H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
-    H.out.append(I('s_barrier', 'barrier'))          # every wave has left the LDS: the wrapper may stage the next output tile
+    H.out.append(I('s_barrier', 'barrier'))          # every wave has left the LDS: the next output tile may be staged
     H.out.append(I('s_nop 7\n\ts_nop 7', 'nop'))
     return H.out, G
+
+
+def generate_drain():
+    """the epilogue of a workgroup's LAST output tile in the overlapped form: the same read-out and the 32 stores, back to back"""
+    G = Gen('nt', True)
+    out = list(G.readout())
+    out.append(I('s_waitcnt vmcnt(0)', 'wait'))
+    out += G.readout_math()
+    for u in range(32):
+        out += G.store_unit(u)
+    out.append(I('s_waitcnt vmcnt(0)', 'wait'))
+    return out, G
+
+
+OVL_MIN_NK = 6
+ACC_IO = ', '.join(f'"+{{a[{acc(i, j)}:{acc(i, j) + 3}]}}"(c[{i}][{j}])' for i in range(8) for j in range(8))
+ACC_OUT = ', '.join(f'"={{a[{acc(i, j)}:{acc(i, j) + 3}]}}"(c[{i}][{j}])' for i in range(8) for j in range(8))
 
 
 def render(stream, G):
@@ -285,30 +396,49 @@ def render(stream, G):
     for ins in stream:
         lines += ins.text.split('\n\t')
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
-    accs = ', '.join(f'"={{a[{acc(i, j)}:{acc(i, j) + 3}]}}"(c[{i}][{j}])' for i in range(8) for j in range(8))
-    srw = ['s_offA', 's_offB', 's_live', 's_cnt']
-    outs = accs + ',\n      ' + f'"+{{s[{SRD["A"]}:{SRD["A"] + 3}]}}"(srdA), "+{{s[{SRD["B"]}:{SRD["B"] + 3}]}}"(srdB),\n      ' + \
+    srw = ['s_offA', 's_offB', 's_live', 's_cnt'] + (['s_crow'] if G.ovl else [])
+    outs = (ACC_IO if G.ovl else ACC_OUT) + ',\n      ' + f'"+{{s[{SRD["A"]}:{SRD["A"] + 3}]}}"(srdA), "+{{s[{SRD["B"]}:{SRD["B"] + 3}]}}"(srdB),\n      ' + \
         ', '.join(f'[{n}] "+&s"({n})' for n in srw) + ', [s_t] "=&s"(s_t)'
-    sin = ['s_ldsw', 's_itA', 's_halfA', 's_ktA', 's_itB', 's_halfB', 's_ktB']
+    sin = ['s_ldsw', 's_itA', 's_halfA', 's_ktA', 's_itB', 's_halfB', 's_ktB'] + (['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'] if G.ovl else [])
     ins_ = ', '.join(f'[{n}] "v"({n})' for n in G.vops()) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
     clob = ', '.join(f'"v{i}"' for i in range(G.n_hand)) + ', "vcc", "scc", "memory"'
-    return (f'// GENERATED by gen_gemm4w.py ({G.layout}) -- do not edit; see that file for the register map and the schedule\n'
+    return (f'// GENERATED by gen_gemm4w.py ({G.layout}{", overlapped bf16 epilogue" if G.ovl else ""}) -- do not edit; see that file for the register map and the schedule\n'
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
 
 
+def render_drain(stream, G):
+    lines = []
+    for ins in stream:
+        lines += ins.text.split('\n\t')
+    body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
+    outs = ACC_IO + ',\n      [s_crow] "+&s"(s_crow)'
+    ins_ = ', '.join(f'[{n}] "v"({n})' for n in ['voffBias', 'voffC', 'colv']) + ',\n      ' + \
+        ', '.join(f'[{n}] "s"({n})' for n in ['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'])
+    clob = ', '.join(f'"v{i}"' for i in range(G.n_hand)) + ', "vcc", "scc", "memory"'
+    return ('// GENERATED by gen_gemm4w.py (epilogue of the last output tile, overlapped form) -- do not edit\n'
+            'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
+
+
+FILES = [(f'gemm4w_body_{l}.inc', l, False) for l in KINDS] + [(f'gemm4w_body_{l}_ovl.inc', l, True) for l in ('nt', 'nn')]
+
+
 def generate_all(outdir):
-    for layout in KINDS:
-        stream, G = generate(layout)
-        with open(os.path.join(outdir, f'gemm4w_body_{layout}.inc'), 'w') as f:
+    for name, layout, ovl in FILES:
+        stream, G = generate(layout, ovl)
+        with open(os.path.join(outdir, name), 'w') as f:
             f.write(render(stream, G))
-        yield layout, stream
+        yield name, stream
+    stream, G = generate_drain()
+    with open(os.path.join(outdir, 'gemm4w_drain_ovl.inc'), 'w') as f:
+        f.write(render_drain(stream, G))
+    yield 'gemm4w_drain_ovl.inc', stream
 
 
 if __name__ == '__main__':
     here = os.path.dirname(os.path.abspath(__file__))
-    for layout, stream in generate_all(here):
+    for name, stream in generate_all(here):
         if '-v' in sys.argv:
             kinds = {}
             for ins in stream:
                 kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
-            print(layout, kinds)
+            print(name, kinds)

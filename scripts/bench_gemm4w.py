@@ -65,6 +65,12 @@ if __name__ == '__main__':
         case(f'{tag} dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, rounds=1)
         case(f'{tag} dgrad proj', 'NN', M, 1024, 1024, rounds=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'wide':     # very wide outputs: automatic plan (256x128 two-per-CU kernel) against the forced 256x256 kernels
+        for pol in (0, 2, 3):
+            case(f'lm head pol {pol}', 'NT', 8184, 50304, 1024, policy=pol, rounds=1)
+            case(f'square 8192 pol {pol}', 'NT', 8192, 8192, 8192, policy=pol, rounds=1)
+            case(f'lm head dgrad pol {pol}', 'NN', 8184, 1024, 50304, policy=pol, rounds=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'one':      # variant runs (scripts/ab_g4w.sh): the main-loop-bound case + one K = 1024 case
         tag = os.path.basename(os.environ.get('PIXPARSE_AMD_LIB', 'default'))
         case(f'{tag} square 8192', 'NT', 8192, 8192, 8192, policy=2)

@@ -380,11 +380,14 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy, big):
         hip.call('crl_gemm_set_big_kernel', 2)
 
 
-@pytest.mark.parametrize('M,N,K', [(600, 520, 192), (256 * 9 + 40, 1024, 1024), (1024, 768, 64), (4096, 4096, 4096 + 64)])
+@pytest.mark.parametrize('M,N,K', [(600, 520, 192), (256 * 9 + 40, 1024, 1024), (1024, 768, 64), (4096, 4096, 4096 + 64), (256 * 70 + 40, 1024, 512), (256 * 150, 512, 576)])
 def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
     """gemm4w.hip (4 waves, one per SIMD, hand-placed main loop) against gemm256.hip (8 waves): every accumulator sums the same products in the
     same order and the epilogue arithmetic is the same, so all three layouts and all six epilogues agree BIT FOR BIT -- ragged M / N tiles, one /
-    odd / even K-tile counts, persistent launches (more tiles than CUs) and split-K weight gradients included"""
+    odd / even K-tile counts, persistent launches (more tiles than CUs) and split-K weight gradients included.  The plain-bf16 launches with whole
+    column tiles and >= 8 K tiles run the OVERLAPPED form (the epilogue of tile T inside the main loop of tile T + 1, crl_gemm_set_overlap): one
+    tile per workgroup (entry + drain statements only), several tiles per workgroup under the dynamic schedule (the last two shapes), and the
+    classic form of the same kernel must all give the same bits"""
     from pixparse_amd import hip, ops
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.1, 2, BF16)
@@ -421,16 +424,26 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
         hip.call('crl_gemm_set_big_kernel', 1)
         got = run()
         again = run()
+        hip.call('crl_gemm_set_overlap', 0)
+        classic = run()
+        hip.call('crl_gemm_set_overlap', 1)
+        ops.gemm_set_schedule(False)
+        static = run()
+        ops.gemm_set_schedule(True)
     finally:
+        hip.call('crl_gemm_set_overlap', 1)
+        ops.gemm_set_schedule(True)
         hip.call('crl_gemm_set_policy', 0)
         hip.call('crl_gemm_set_big_kernel', 2)
     ref = x.float() @ w.float().t() + bias.to(BF16).float()
     ref[:, :min(N, 256)] *= 0.25
     close(got[0], ref, 1e-2, 1e-2, '4w NT vs fp32')
     close(got[8], dy.float().t() @ x.float(), 2e-3, 0.2, '4w TN vs fp32')
-    for n, a, b, c in zip(names, want, got, again):
+    for n, a, b, c, d, e in zip(names, want, got, again, classic, static):
         assert torch.equal(a, b), f'{n}: 4-wave kernel differs from the 8-wave kernel (max abs {(a.float() - b.float()).abs().max().item():.3e})'
         assert torch.equal(b, c), f'{n}: 4-wave kernel is not reproducible'
+        assert torch.equal(b, d), f'{n}: overlapped and classic epilogue differ'
+        assert torch.equal(b, e), f'{n}: dynamic and static tile walk differ'
 
 
 def test_gemm_dynamic_tile_schedule(dev):
