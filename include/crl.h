@@ -62,6 +62,11 @@ int crl_gemm_set_big_kernel(int which);
 /* 1 (default): plain-bf16 NT / NN launches of the 4-wave kernel whose columns are whole tiles run the epilogue of output tile T inside the main loop
  * of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles.  Same results bit for bit.  Process-wide. */
 int crl_gemm_set_overlap(int on);
+/* 1 (default 0: measured slower, profiles/r5_gemm_async_xcd.txt): the remainder rows of a wave-quantisation cut (NT / NN launches whose last round of 256x256 tiles would be less than 60 % full) run
+ * BESIDE the persistent launch on a side stream of the library, forked from / joined to the caller's stream by events around the two launches
+ * (never while the caller's stream is being captured); 0: the round-3 cost model and serial launches.  Which rows take which kernel depends
+ * on this switch and on the problem only, never on a timing.  Process-wide. */
+int crl_gemm_set_async_remainder(int on);
 /* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
    < 0 = never cut.  Process-wide. */
 int crl_gemm_set_quant_cost(float c);
