@@ -370,7 +370,8 @@ static RemSide* rem_side() {
   return &rs;
 }
 static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
-  if (layout != CRL_TN && g_quant_cost >= 0.f && g_rem_async) {
+  if (layout == CRL_TN || g_quant_cost < 0.f) return -1;      // (the cut is along the rows of a row-major A: never for the weight-gradient layout)
+  if (g_rem_async) {
     const int64_t ntn_ = (N + 255) / 256, ncu_ = crl_gemm_cus(), tiles = ((M + 255) / 256) * ntn_;
     const int64_t whole = tiles / ncu_, part = tiles - whole * ncu_;
     if (whole < 1 || part == 0 || 10 * part >= 6 * ncu_) return -1;
@@ -661,9 +662,14 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
         default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, sr);
       }
     };
-    int rc = launch_rest();                       // enqueued FIRST: its workgroups are placed before the persistent kernel takes every CU
+#ifndef G_REM_FIRST
+#define G_REM_FIRST 1
+#endif
+    int rc = 0;
+    if (!G_REM_FIRST && !e_join) rc = big_launch(layout, epilogue, big, 1, s);
+    if (!rc) rc = launch_rest();                  // (async form) enqueued FIRST: its workgroups are placed before the persistent kernel takes every CU
     if (e_join && hipEventRecord(e_join, sr) != hipSuccess) { crl_set_error("crl_gemm_bf16: cannot record the join event"); rc = rc ? rc : -2; }
-    if (!rc) rc = big_launch(layout, epilogue, big, 1, s);
+    if (!rc && (G_REM_FIRST || e_join)) rc = big_launch(layout, epilogue, big, 1, s);
     if (e_join && hipStreamWaitEvent(s, e_join, 0) != hipSuccess) { crl_set_error("crl_gemm_bf16: cannot join the side stream"); rc = rc ? rc : -2; }
     return rc;
   }

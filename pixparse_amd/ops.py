@@ -36,11 +36,29 @@ def gemm(layout: int, epi: int, M: int, N: int, K: int, A: torch.Tensor, lda: in
     _chk(A, BF16, 'gemm A')
     _chk(B, BF16, 'gemm B')
     ws = None
+    _gemm_env()
     wsb = hip.query('crl_gemm_ws_bytes', layout, epi, M, N, K)   # wgrad split-K slabs, or the split remainder rows of a forward / dgrad GEMM
     if wsb:
         ws = _gemm_scratch.get(wsb, A.device)
     hip.call('crl_gemm_bf16', layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(C), ldc, _p(aux), ldaux,
              _p(resid), ldr, float(colscale), int(colscale_cols), _p(ws), wsb, _stream())
+
+
+_gemm_env_applied = False
+
+
+def _gemm_env():
+    """A/B switches of the GEMM dispatch, read once: PIXPARSE_AMD_GEMM_BIG=0|1|2 (crl_gemm_set_big_kernel: 8-wave / 4-wave / per launch),
+    PIXPARSE_AMD_GEMM_OVERLAP=0|1 (crl_gemm_set_overlap), PIXPARSE_AMD_GEMM_ASYNC_REM=0|1 (crl_gemm_set_async_remainder)"""
+    global _gemm_env_applied
+    if _gemm_env_applied:
+        return
+    _gemm_env_applied = True
+    import os
+    for env, fn in (('PIXPARSE_AMD_GEMM_BIG', 'crl_gemm_set_big_kernel'), ('PIXPARSE_AMD_GEMM_OVERLAP', 'crl_gemm_set_overlap'),
+                    ('PIXPARSE_AMD_GEMM_ASYNC_REM', 'crl_gemm_set_async_remainder')):
+        if os.environ.get(env):
+            hip.call(fn, int(os.environ[env]))
 
 
 _calibrated = {}
@@ -139,6 +157,9 @@ class Scratch:
             if Scratch.frozen and self.buf is not None:
                 self.retired.append(self.buf)
             self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            import os
+            if os.environ.get('PIXPARSE_AMD_POISON', '0') == '1':    # debug aid (see layers/engines.py Buffers)
+                self.buf.fill_(255)
         return self.buf
 
 

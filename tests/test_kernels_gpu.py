@@ -446,6 +446,28 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
         assert torch.equal(b, e), f'{n}: dynamic and static tile walk differ'
 
 
+@pytest.mark.parametrize('big', [0, 1, 2])
+def test_wgrad_with_a_partial_last_round_is_never_row_cut(dev, big):
+    """a weight gradient whose output has more 256x256 tiles than CUs and a partial last round (71 x 4 tiles, contraction 2048: the shape class
+    of the LM-head weight gradient, 197 x 4 tiles): the wave-quantisation cut is along the rows of a ROW-MAJOR A operand and must never be
+    applied to the k-major weight-gradient layout (round 5 regression: an edit of quant_rows dropped that guard; the remainder launch then
+    read A with the wrong strides -- illegal addresses at cfg-3, run-to-run differences in the loss)"""
+    from pixparse_amd import hip, ops
+    Kc, Mo, No = 2048, 256 * 70 + 40, 1024
+    dy = rnd((Kc, Mo), dev, 1.0, 1, BF16)
+    x = rnd((Kc, No), dev, 1.0, 2, BF16)
+    hip.call('crl_gemm_set_big_kernel', big)
+    try:
+        dw = torch.full((Mo, No), 1.0, device=dev)
+        ops.linear_wgrad(dy, x, dw, accumulate=True)
+        dw2 = torch.full((Mo, No), 1.0, device=dev)
+        ops.linear_wgrad(dy, x, dw2, accumulate=True)
+    finally:
+        hip.call('crl_gemm_set_big_kernel', 2)
+    assert torch.equal(dw, dw2)
+    close(dw, 1.0 + dy.float().t() @ x.float(), 2e-3, 0.5, 'TN, 284 tiles, partial last round')
+
+
 def test_gemm_dynamic_tile_schedule(dev):
     """persistent GEMMs (more tiles than resident workgroups) under the dynamic tile scheduler: bit-identical to the static walk for all
     three layouts and both persistent kernels; the ticket counters are left zeroed by every launch (80 launches through a pool of 64
