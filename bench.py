@@ -444,7 +444,8 @@ def main():
                     pk = measured_gemm_peak(env.device)
                     live_prof['peak_measured'] = round(pk, 1)
                     live_prof['frac_measured'] = round(live_prof['achieved'] / pk, 4)
-                    live_prof['peak_measured_what'] = 'this library\'s 8192^3 bf16 GEMM, 200 launches back to back (sustained, power-limited clock)'
+                    live_prof['peak_measured_what'] = ('this library\'s 8192^3 bf16 GEMM (round 5: the 4-wave one-wave-per-SIMD kernel, grouped tile order, overlapped epilogue), '
+                                                       '200 launches back to back (sustained clock); the vendor GEMM on the same boxes: profiles/r5_yardstick.txt')
                     out['step_frac_of_measured_peak'] = round(step_tflops / pk, 4)
                 except Exception as e:
                     live_prof['peak_measured'] = {'error': repr(e)}
