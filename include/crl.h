@@ -59,8 +59,9 @@ int crl_gemm_set_policy(int policy);
  * (gemm4w.hip, round 5) where a workgroup walks >= 32 K tiles behind a store-only epilogue (weight gradients, long-K dgrads), else the 8-wave
  * 8-phase kernel (gemm256.hip); 1 / 0 force one of them.  Same results bit for bit; tests / same-box A-B.  Process-wide. */
 int crl_gemm_set_big_kernel(int which);
-/* 1 (default): plain-bf16 NT / NN launches of the 4-wave kernel whose columns are whole tiles run the epilogue of output tile T inside the main loop
- * of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles.  Same results bit for bit.  Process-wide. */
+/* 1 (default): plain-bf16 NT / NN launches of the 4-wave kernel with whole column tiles and at least three rounds of tiles run the epilogue of output
+ * tile T inside the main loop of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles; bit 1 (2 | 3): also the
+ * fp32-residual epilogue (measured slower, off); 7: both forms for ANY number of tiles (tests).  Same results bit for bit.  Process-wide. */
 int crl_gemm_set_overlap(int on);
 /* 1 (default 0: measured slower, profiles/r5_gemm_async_xcd.txt): the remainder rows of a wave-quantisation cut (NT / NN launches whose last round of 256x256 tiles would be less than 60 % full) run
  * BESIDE the persistent launch on a side stream of the library, forked from / joined to the caller's stream by events around the two launches

@@ -477,6 +477,9 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
 static int g4_overlap = G4_OVERLAP;
 bool crl_gemm4w_can_overlap(int layout, int epi, const GemmArgs& a, int nsplit) {
   if (!g4_overlap || nsplit != 1 || (a.N % 256) != 0 || (a.K % 64) != 0 || a.K / 64 < 8) return false;
+  // a workgroup with one or two tiles pays the entry + drain statements for nothing (cfg-2, M = 19 208: 27.3 ms per step overlapped against
+  // 27.05 classic, profiles/r5_cfg2_ab.txt): the overlapped form from three rounds of tiles on
+  if ((int64_t)a.ntm * a.ntn < 3 * (int64_t)crl_gemm_cus() && g4_overlap != 7) return false;
   if (epi == CRL_EPI_BF16) return layout != CRL_TN && (a.ldc % 8) == 0;
   if (epi == CRL_EPI_F32_RESID) return (g4_overlap & 2) && layout == CRL_NT && (a.ldc % 4) == 0 && (a.ldr % 4) == 0 && a.resid != nullptr;
   return false;
@@ -541,7 +544,7 @@ int launch4w_epi(const GemmArgs& a, int epi, int nsplit, hipStream_t s) {
 }  // namespace
 
 // called by crl_gemm_bf16 (gemm.hip): same contract as crl_gemm256_launch
-extern "C" int crl_gemm_set_overlap(int on) { g4_overlap = on == 1 ? 3 : (on & 3); return 0; }    // 0 off, 1 = everything, 2 | 3 = bit mask (1 bf16, 2 residual)
+extern "C" int crl_gemm_set_overlap(int on) { g4_overlap = on & 7; return 0; }    // 0 off; bit 0 the plain bf16 epilogue, bit 1 the fp32-residual epilogue; 7 = both, also for launches of fewer than three rounds of tiles (tests)
 bool crl_gemm4w_overlaps(int layout, int epi, const gemmc::GemmArgs& a, int nsplit) { return crl_gemm4w_can_overlap(layout, epi, a, nsplit); }
 int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
   if (crl_gemm4w_can_overlap(layout, epi, a, nsplit)) {

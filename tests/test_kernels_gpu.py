@@ -422,11 +422,12 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
         hip.call('crl_gemm_set_big_kernel', 0)
         want = run()
         hip.call('crl_gemm_set_big_kernel', 1)
+        hip.call('crl_gemm_set_overlap', 7)      # every overlapped form (plain bf16 and fp32 residual), also for launches of fewer than three rounds of tiles
         got = run()
         again = run()
         hip.call('crl_gemm_set_overlap', 0)
         classic = run()
-        hip.call('crl_gemm_set_overlap', 1)
+        hip.call('crl_gemm_set_overlap', 7)
         ops.gemm_set_schedule(False)
         static = run()
         ops.gemm_set_schedule(True)
