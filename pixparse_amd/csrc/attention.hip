@@ -276,14 +276,12 @@ __global__ __launch_bounds__(256, FWD_OCC) void attn_fwd_kernel(const AttnArgs a
 //     true row maximum and re-centres O, l and the seed exactly like the kernel above;
 // which leaves 32 v_exp + 32 adds + 16 conversions per block on the fast path.  Same results up to the rounding of p (the reference
 // only shifts every probability of a row and its sum by the same power of two).
-template <bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, 3) void attn_fwd_pre_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+// the body for the 128 queries qt * 128 .. of (batch, head) bh; `smem` = 32 KiB of LDS nobody else touches (entered and left by all four waves)
+template <bool CAUSAL, bool DROP>
+__device__ __forceinline__ void fwd_pre_block(const AttnArgs& a, char* smem, int bh, int qt) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31, hh = lane >> 5;
-  int bh, qt;
-  block_to_bh_tile(blockIdx.x, a.nqt, a.B * a.H, bh, qt);
   const int b = bh / a.H, h = bh % a.H;
   const int off = a.Nk - a.Nq;
 
@@ -417,6 +415,169 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_pre_kernel(const AttnArgs a) 
       *reinterpret_cast<uint2*>(op + 32 + dv) = uint2{pack_bf2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv), pack_bf2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv)};
     }
     if (hh == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qabs] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : -INFINITY;
+  }
+}
+
+template <bool CAUSAL, bool DROP = false>
+__global__ __launch_bounds__(256, 3) void attn_fwd_pre_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];
+  int bh, qt;
+  block_to_bh_tile(blockIdx.x, a.nqt, a.B * a.H, bh, qt);
+  fwd_pre_block<CAUSAL, DROP>(a, smem, bh, qt);
+}
+
+// ======================================================================================= forward, one wave per SIMD (hand-placed stream)
+// 256 queries per workgroup, 64 per wave (two 32-query blocks: every K / V^T fragment read from LDS feeds two MFMAs), the main loop is the
+// generated statement attn_fwd4w_body.inc (gen_attn_fwd4w.py: software pipeline over quarter tiles, two v_exp + one conversion per MFMA gap, row
+// sums on the matrix pipe, K / V by LDS-DMA two tiles ahead into a ring of four slots).  Non-causal, no dropout, q prescaled, Nk >= 128.
+// The softmax reference of a row is the exact maximum of its scores over the FIRST key tile and never moves (probabilities up to 2^127 keep their
+// relative precision in bf16 / fp32); a block in which any row ends with a non-finite sum or output is run again by the whole workgroup with the
+// moving-maximum body above (fwd_pre_block) -- results then equal attn_fwd_pre_kernel's.
+#ifndef F4W_STAMPS
+#define F4W_STAMPS 0
+#endif
+#ifndef F4W_OCC2
+#define F4W_OCC2 0      // 1: also build the two-waves-per-SIMD form (experimental: see DESIGN.md)
+#endif
+constexpr int F4W_LDS = 4 * 16384;
+#if F4W_STAMPS      // diagnostic builds (scripts/ab_f4w.sh): cycles of the stream statement per workgroup (wave 0), s_memtime
+__device__ unsigned long long* g_f4w_stamps = nullptr;
+#endif
+// OCC = 1: one wave per SIMD, 512 registers per wave (attn_fwd4w_body.inc); OCC = 2: the same pipeline in 256 registers (single fragment sets re-read
+// behind their last use, MFMA-only operands in the accumulator half) so that TWO workgroups share a CU: a lone wave issues its v_exp, conversions, LDS
+// reads and MFMAs strictly one after the other (~1500 issue cycles per key tile against 1152 of matrix-pipe time), two waves per SIMD overlap them.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, int force_fallback) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31, hh = lane >> 5;
+  const int nqb = (a.Nq + 255) / 256;
+  int bh, qt;
+  block_to_bh_tile(blockIdx.x, nqb, a.B * a.H, bh, qt);
+  const int b = bh / a.H, h = bh % a.H;
+
+  const u16* qp = a.q + b * a.q_bs + h * 64;
+  const u32x4 srdK = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
+  const u32x4 srdV = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
+  const uint32_t sbase = lds_addr_of(smem4);
+  const LaneAddr la = make_lane_addr(lane);
+  const StageOff sk = make_stage_off(tid, a.k_rs), sv = make_stage_off(tid, a.v_rs);
+  const int q0 = qt * 256 + wave * 64;
+  const int nt = (a.Nk + 63) / 64;
+
+  // tiles 0 and 1 -> slots 0 and 1
+  for (int t = 0; t < 2; ++t) {
+    stage64(srdK, sbase + t * 16384, sk, t * 64, a.k_rs, wave);
+    stage64(srdV, sbase + t * 16384 + 8192, sv, t * 64, a.v_rs, wave);
+  }
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = min(q0 + 32 * qb + qi, a.Nq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)qrow * a.q_rs + 16 * ks + 8 * hh);
+  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile 0 (this wave's pieces; the Q loads are older)
+  __syncthreads();
+  // exact row maxima over the first key tile (Nk >= 64: no mask)
+  float m[2];
+  f32x16 seed0, seed1;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s0 = mfma32(frag_row(smem4, la, 0, ks), qf[qb][ks], s0);
+      s1 = mfma32(frag_row(smem4, la, 32, ks), qf[qb][ks], s1);
+    }
+    float mx = max3f(s0[0], s1[0], -INFINITY);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = max3f(mx, s0[r], s1[r]);
+    mx = max3f(mx, swap32(mx), -INFINITY);
+    m[qb] = mx;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { seed0[r] = -m[0]; seed1[r] = -m[1]; }
+  const float negm0 = -m[0], negm1 = -m[1], neginf = -INFINITY;
+  bf16x8 ones;
+  {
+    const int mrow = lane & 15, g = lane >> 4;
+    const float one = ((mrow == 1 && (g & 1) == 0) || (mrow == 2 && (g & 1) == 1)) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)one;
+  }
+  f32x16 o00 = zero16(), o01 = zero16(), o10 = zero16(), o11 = zero16();
+  f32x4 lsum0 = f32x4{0.f, 0.f, 0.f, 0.f}, lsum1 = f32x4{0.f, 0.f, 0.f, 0.f};      // row sums on the matrix pipe ...
+  float ps00 = 0.f, ps01 = 0.f, ps10 = 0.f, ps11 = 0.f;                              // ... or as VALU adds (generator option lsum=valu)
+  {
+    const bf16x8 q00 = qf[0][0], q01 = qf[0][1], q02 = qf[0][2], q03 = qf[0][3], q10 = qf[1][0], q11 = qf[1][1], q12 = qf[1][2], q13 = qf[1][3];
+    const uint32_t akr0 = sbase + la.row[0], akr1 = sbase + la.row[1], akr2 = sbase + la.row[2], akr3 = sbase + la.row[3];
+    const uint32_t avt00 = sbase + la.tr[0][0], avt01 = sbase + la.tr[0][1], avt10 = sbase + la.tr[1][0], avt11 = sbase + la.tr[1][1];
+    const uint32_t voffK = sk.v, voffV = sv.v;
+    const int limlane = (a.Nk - (nt - 1) * 64) - 4 * hh;      // last tile: key row 32 kh + (r & 3) + 8 (r >> 2) of this lane half is valid iff < limlane
+    const uint32_t s_ldsw = sbase + (uint32_t)wave * 1024u;
+    const uint32_t s_k32 = (uint32_t)(32 * a.k_rs * 2), s_v32 = (uint32_t)(32 * a.v_rs * 2);
+    const uint32_t s_kstep = (uint32_t)(64 * a.k_rs * 2), s_vstep = (uint32_t)(64 * a.v_rs * 2);
+    uint32_t s_koff = 2u * s_kstep, s_voff = 2u * s_vstep, s_cnt = (uint32_t)(nt - 1), s_t, s_slot;
+#if F4W_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+    if constexpr (OCC == 1) {
+#include "attn_fwd4w_body.inc"
+    } else {
+#if F4W_OCC2
+#include "attn_fwd2x_body.inc"
+#endif
+    }
+#if F4W_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+    if (g_f4w_stamps && tid == 0) g_f4w_stamps[blockIdx.x] = st1 - st0;
+#endif
+  }
+  // ---- epilogue: l of query (lane & 31) sits in lanes 0..15, register 1 (queries 0..15) / 2 (queries 16..31) of the row-sum accumulators
+  float chk = 0.f;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#if F4W_LSUM_VALU
+    float l = qb ? ps10 + ps11 : ps00 + ps01;
+    l += swap32(l);
+#else
+    const f32x4 ls = qb ? lsum1 : lsum0;
+    const float a1 = __shfl(ls[1], lane & 15, 64), a2 = __shfl(ls[2], lane & 15, 64);
+    const float l = (lane & 16) ? a2 : a1;
+#endif
+    const float inv = 1.f / l;
+    chk = __builtin_fmaf(l, 0.f, chk);
+    const f32x16& oa = qb ? o10 : o00;
+    const f32x16& ob = qb ? o11 : o01;
+    const int qabs = q0 + 32 * qb + qi;
+    float va[16], vb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      va[r] = oa[r] * inv; vb[r] = ob[r] * inv;
+      chk = __builtin_fmaf(va[r], 0.f, chk);
+      chk = __builtin_fmaf(vb[r], 0.f, chk);
+    }
+    if (qabs < a.Nq) {
+      u16* op = a.out + b * a.o_bs + (int64_t)qabs * a.o_rs + h * 64;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dv = 8 * g4 + 4 * hh;
+        *reinterpret_cast<uint2*>(op + dv) = uint2{pack_bf2(va[4 * g4], va[4 * g4 + 1]), pack_bf2(va[4 * g4 + 2], va[4 * g4 + 3])};
+        *reinterpret_cast<uint2*>(op + 32 + dv) = uint2{pack_bf2(vb[4 * g4], vb[4 * g4 + 1]), pack_bf2(vb[4 * g4 + 2], vb[4 * g4 + 3])};
+      }
+      if (hh == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qabs] = (m[qb] + __builtin_amdgcn_logf(l)) * LN2;
+    }
+  }
+  // any non-finite l or output (NaN * 0 = NaN) -> the workgroup runs its two 128-query halves again with the moving maximum
+#ifdef F4W_NO_FALLBACK      // timing-only variants of the stream (scripts/ab_f4w.sh) produce garbage on purpose
+  chk = 0.f;
+#endif
+  if (__syncthreads_or((!(chk == 0.f)) || force_fallback)) {
+    fwd_pre_block<false, false>(a, smem4, bh, 2 * qt);
+    __syncthreads();
+    if ((2 * qt + 1) * 128 < a.Nq) fwd_pre_block<false, false>(a, smem4, bh, 2 * qt + 1);
   }
 }
 
@@ -1154,6 +1315,18 @@ int check_common(const char* who, int B, int H, int Nq, int Nk, int64_t rs_min) 
 
 }  // namespace
 
+#if F4W_STAMPS
+extern "C" int crl_debug_f4w_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_f4w_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+static int g_fwd_mode = 0;      // 0 auto (hand-placed stream where it applies), 1 the 32-queries-per-wave kernels only, 2 stream + forced fallback, 3 / 4 stream with one / two waves per SIMD
+extern "C" int crl_attn_fwd_set_mode(int mode) {
+  if (mode < 0 || mode > 4) { crl_set_error("crl_attn_fwd_set_mode: 0 auto, 1 compiler-scheduled kernels only, 2 hand-placed stream with its fallback forced (tests), 3 / 4 the stream with one / two waves per SIMD"); return -1; }
+  g_fwd_mode = mode;
+  return 0;
+}
+
 extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                             const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs,
                             float* lse, int B, int H, int Nq, int Nk, float scale, int causal, int q_prescaled,
@@ -1178,7 +1351,20 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   // algorithmic FLOPs: QK^T and PV, 2 x 2 x Nq x Nk x 64 per head (a causal mask halves them when Nq == Nk)
   const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
   CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
-  if (q_prescaled) {       // base-2 logits straight from the MFMAs: the seeded / lazy-maximum kernel (`scale` is not used)
+  if (q_prescaled && !drop && !causal && g_fwd_mode != 1 && Nk >= 128) {
+    // the one-wave-per-SIMD stream: 256 queries per workgroup (mode 2: every block also runs its moving-maximum fallback -- tests)
+    static bool configured = false;
+    if (!configured) {
+      for (const void* f : {reinterpret_cast<const void*>(&attn_fwd4w_kernel<1>), reinterpret_cast<const void*>(&attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1>)}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4W_LDS);
+        if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, F4W_LDS, hipGetErrorString(e)); return -2; }
+      }
+      configured = true;
+    }
+    const unsigned g4 = (unsigned)((Nq + 255) / 256) * B * H;
+    if (g_fwd_mode == 4 && F4W_OCC2) attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, 0);
+    else attn_fwd4w_kernel<1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
+  } else if (q_prescaled) {       // base-2 logits straight from the MFMAs: the seeded / lazy-maximum kernel (`scale` is not used)
     if (drop) { if (causal) attn_fwd_pre_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a); else attn_fwd_pre_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a); }
     else if (causal) attn_fwd_pre_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);
     else attn_fwd_pre_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a);

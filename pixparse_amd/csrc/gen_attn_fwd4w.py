@@ -1,0 +1,409 @@
+#!/usr/bin/env python3
+"""Generates attn_fwd4w_body.inc: the hand-placed gfx950 instruction stream of the one-wave-per-SIMD attention forward (attention.hip:
+attn_fwd4w_kernel; non-causal, head_dim 64, q prescaled by scale * log2 e).
+
+Workgroup = 256 queries of one (batch, head) = 4 waves, ONE WAVE PER SIMD with the whole 512-entry register file; a wave owns 64 queries = two
+32-query blocks qb, so every K row fragment and every V^T fragment it reads from LDS feeds TWO v_mfma_f32_32x32x16_bf16 (the 32-queries-per-wave
+kernel reads 1 KiB of LDS per MFMA = the whole LDS bandwidth of the CU at the MFMA rate; this one half of it).  Per 64-key tile a wave issues
+  16 MFMAs  S^T = K . Q^T + seed   (query on the lane, the 32 keys of a half kh in the 16 accumulator registers; seed = -m in every register)
+  64 v_exp_f32 (in place) + 32 v_cvt_pk_bf16_f32 -> the P^T fragments (accumulator order = the k order of the transposed V reads: no lane exchange)
+  16 MFMAs  O^T += V^T . P^T      (O in a[0:63])
+   8 v_mfma_f32_16x16x32_bf16  L += ONES . P^T: the row sums on the matrix pipe (a 16-cycle MFMA instead of 8 VALU adds of 4 cycles: the
+     stream is bound by VALU ISSUE, not by the pipe).  A lane of the 16x16x32 B operand holds query (lane & 15) + 16 (k-group & 1), so the ONES
+     operand has row 1 = 1 on k-groups 0 / 2, row 2 = 1 on k-groups 1 / 3: L[1][n] = row sum of query n, L[2][n] = of query n + 16 (a[64:71]).
+The reference m is the exact row maximum over the FIRST key tile (the wrapper computes it) and never moves: probabilities are 2^(s - m), up to
+2^127 -- bf16 and fp32 have the exponent range, the relative precision of p, l and O does not depend on it.  A row whose later scores exceed
+its first tile's maximum by more than 127 (or whose sums overflow) ends with a non-finite l or O: the wrapper detects that at the end of the
+block and the WORKGROUP re-runs the block with the moving-maximum kernel body (attn_fwd_pre: never seen outside the forced test).
+
+Software pipeline over quarters k = 4 t + j (tile t, key half kh = j >> 1, query block qb = j & 1), one step per quarter:
+  step k:  MFMAs  QK(k) [4]  |  PV(k - 2) [4] + L(k - 2) [2 small]      VALU: exp / cvt of quarter k - 1 (two v_exp + one cvt per 32-cycle gap)
+MFMA order QK0 PVa QK1 PVb La QK2 PVc QK3 PVd Lb: no MFMA follows one that writes its accumulator.  Fragment registers are double sets indexed by
+kh; LDS reads of a set are issued while the other set is in use:
+  step 4t    : K[kh1](t) ks 0,1 ; V[kh0](t) s 0          step 4t + 2: V[kh1](t) s 0
+  step 4t + 1: K[kh1](t) ks 2,3 ; V[kh0](t) s 1          step 4t + 3: BARRIER(t + 1) ; K[kh0](t + 1) ; V[kh1](t) s 1
+K / V tiles (8 KiB + 8 KiB, the swizzled 64 x 64 image of attn_frag.h) arrive by LDS-DMA two tiles ahead into a ring of four 16-KiB slots (64 KiB:
+every ds_read offset is an immediate); each wave issues 4 of the 16 pieces of a tile, one per step; one barrier per tile (tile t + 1 landed for
+every wave, slot of tile t - 2 free).  Tiles past the end arrive as zeros (bounds-checked descriptor).  The loop is unrolled four-fold (ring
+period); the first tile is peeled (nothing to exponentiate / accumulate yet); the LAST tile runs in a tail with register-based slot addressing whose
+S chains start from seed-or-minus-infinity tuples (keys >= Nk masked: built in the tail, 32 VALU per quarter), followed by the drain of the pipeline.
+
+Registers (hand-allocated v[0 : N_HAND); the wrapper's operands -- Q fragments, seeds, ONES, lane addresses -- live above):
+  v[0:31]   K row fragments [kh][ks] x 4        v[32:63]  V^T fragments [kh][2 s + db] x 4
+  v[64:95]  S / P accumulators, two sets        v[96:111] P^T bf16 fragments, two sets x [s] x 4
+  v[112:143] masked seed tuples (tail)          v[144:151] slot-relative lane addresses (tail)
+  a[0:63]   O^T [qb][db] x 16                   a[64:71]  L [qb] x 4
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_gemm4w import I, Hazards, op, vregs  # noqa: E402
+
+OPTS = dict(kv.split('=') if '=' in kv else (kv, '1') for kv in filter(None, os.environ.get('F4W_OPTS', '').split(',')))
+FDROP = set(filter(None, os.environ.get('F4W_DROP', '').split(',')))      # timing-only builds (WRONG results): exp cvt dsread dma lsum
+
+V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = 0, 32, 64, 96, 112, 144, 152
+A_O, A_L = 0, 64
+OCC2 = False        # set by generate(occ2=True): the two-waves-per-SIMD form (256 registers per wave) -- see the header
+FRAG_ACC = OPTS.get('fragacc', '0') == '1'      # K / V fragments in the accumulator half of the register file (a[72:135]) instead of v[0:63]
+FP = 'a' if FRAG_ACC else 'v'
+LSUM_VALU = OPTS.get('lsum', 'mfma') == 'valu'      # row sums as fp32 VALU adds of the unrounded probabilities (two chains per query block) instead of MFMAs
+if FRAG_ACC:
+    V_KF, V_VF = 72, 104
+
+
+def set_map(occ2):
+    """register map of the form being generated"""
+    global OCC2, V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND
+    OCC2 = occ2
+    if occ2:
+        V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = 0, 16, 32, 64, None, 80, 88
+    else:
+        V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = (72 if FRAG_ACC else 0), (104 if FRAG_ACC else 32), 64, 96, 112, 144, 152
+RING = 4
+SLOT = 16384
+
+
+def KF(kh, ks):
+    return V_KF + (0 if OCC2 else 16 * kh) + 4 * ks
+
+
+def VF(kh, f):
+    return V_VF + (0 if OCC2 else 16 * kh) + 4 * f
+
+
+def SB(b):
+    return V_S + 16 * (b & 1)
+
+
+def PB(b, s):
+    return V_P + 8 * (b & 1) + 4 * s
+
+
+def AO(qb, db):
+    return A_O + 16 * (2 * qb + db)
+
+
+def AL(qb):
+    return A_L + 4 * qb
+
+
+def vt(b, n):
+    return f'v[{b}:{b + n - 1}]'
+
+
+def ft(b, n):
+    return f'{FP}[{b}:{b + n - 1}]'
+
+
+def fregs(b, n):
+    return {f'{FP}{i}' for i in range(b, b + n)}
+
+
+def at(b, n):
+    return f'a[{b}:{b + n - 1}]'
+
+
+# ---------------------------------------------------------------------------------------------------------------- instruction builders
+def mfma_qk(k, ks, cm=None):
+    """S[k & 1] (+)= K[kh][ks] . Q[qb][ks]^T; the chain starts from the seed tuple of the query block (or the masked tuple `cm`, tail)"""
+    j = k & 3
+    kh, qb = j >> 1, j & 1
+    d = SB(k)
+    if ks == 0:
+        c = vt(cm, 16) if cm is not None else op(f'seed{qb}')
+    else:
+        c = vt(d, 16)
+    rd = fregs(KF(kh, ks), 4) | (vregs(cm, 16) if (cm is not None and ks == 0) else set())
+    return I(f'v_mfma_f32_32x32x16_bf16 {vt(d, 16)}, {ft(KF(kh, ks), 4)}, {op(f"q{qb}{ks}")}, {c}', 'mfma', reads=rd, writes=vregs(d, 16))
+
+
+def mfma_pv(k, s, db):
+    """O[qb][db] += V^T[kh][s][db] . P(k)[s]"""
+    j = k & 3
+    kh, qb = j >> 1, j & 1
+    o = AO(qb, db)
+    return I(f'v_mfma_f32_32x32x16_bf16 {at(o, 16)}, {ft(VF(kh, 2 * s + db), 4)}, {vt(PB(k, s), 4)}, {at(o, 16)}', 'mfma',
+             reads=fregs(VF(kh, 2 * s + db), 4) | vregs(PB(k, s), 4))
+
+
+def mfma_l(k, s):
+    qb = k & 1
+    return I(f'v_mfma_f32_16x16x32_bf16 {at(AL(qb), 4)}, {op("ones")}, {vt(PB(k, s), 4)}, {at(AL(qb), 4)}', 'mfma', reads=vregs(PB(k, s), 4))
+
+
+def v_exp(k, r):
+    x = SB(k) + r
+    return I(f'v_exp_f32 v{x}, v{x}', 'valu', reads={f'v{x}'}, writes={f'v{x}'}, tag='exp')
+
+
+def v_cvt(k, pair):
+    x = SB(k) + 2 * pair
+    d = PB(k, pair >> 2) + (pair & 3)
+    return I(f'v_cvt_pk_bf16_f32 v{d}, v{x}, v{x + 1}', 'valu', reads={f'v{x}', f'v{x + 1}'}, writes={f'v{d}'}, tag='cvt')
+
+
+def v_sum(k, r):
+    """psum[qb][r & 1] += p(k)[r]"""
+    x = SB(k) + r
+    acc = op(f'ps{k & 1}{r & 1}')
+    return I(f'v_add_f32 {acc}, {acc}, v{x}', 'valu', reads={f'v{x}'}, tag='sum')
+
+
+class Addr:
+    """LDS addressing of a tile: in the unrolled loop the wrapper's lane addresses + slot immediates, in the tail the slot-relative copies"""
+    def __init__(self, slot=None):
+        self.slot = slot
+
+    def k(self, ks):
+        return (op(f'akr{ks}'), self.slot * SLOT) if self.slot is not None else (f'v{V_TA + ks}', 0)
+
+    def v(self, db, half):
+        return (op(f'avt{db}{half}'), self.slot * SLOT) if self.slot is not None else (f'v{V_TA + 4 + 2 * db + half}', 0)
+
+
+def read_k(addr, kh_src, kh_dst, ks, tag):
+    reg, imm = addr.k(ks)
+    b = KF(kh_dst, ks)
+    return [I(f'ds_read_b128 {ft(b, 4)}, {reg} offset:{imm + 4096 * kh_src}', 'ds', writes=fregs(b, 4), tag=tag)]
+
+
+def read_v(addr, kh, s, db, tag):
+    b = VF(kh, 2 * s + db)
+    out = []
+    for half in range(2):
+        reg, imm = addr.v(db, half)
+        out.append(I(f'ds_read_b64_tr_b16 {ft(b + 2 * half, 2)}, {reg} offset:{imm + 8192 + 4096 * kh + 2048 * s}', 'ds', writes=fregs(b + 2 * half, 2), tag=tag))
+    return out
+
+
+def dma_piece(slot, n, tag):
+    """piece n of the wave's four of a tile: 0 / 1 = K rows 8 w.. / 32 + 8 w.., 2 / 3 = V likewise"""
+    o = 'k' if n < 2 else 'v'
+    out = [I(f's_add_u32 m0, {op("s_ldsw")}, {slot * SLOT + (8192 if n >= 2 else 0) + (4096 if n & 1 else 0)}', 'salu')]
+    if n & 1:
+        out.append(I(f's_add_u32 {op("s_t")}, {op(f"s_{o}off")}, {op(f"s_{o}32")}', 'salu'))
+        soff = op('s_t')
+    else:
+        out.append(I('s_nop 0', 'salu'))
+        soff = op(f's_{o}off')
+    out.append(I(f'buffer_load_dwordx4 {op(f"voff{o.upper()}")}, {op(f"srd{o.upper()}")}, {soff} offen lds', 'dma', tag=tag))
+    if n & 1:
+        out.append(I(f's_add_u32 {op(f"s_{o}off")}, {op(f"s_{o}off")}, {op(f"s_{o}step")}', 'salu'))
+    return out
+
+
+BIG = [0, 1, 2, 3, 5, 6, 7, 8]       # MFMA positions of a step that are 32-cycle MFMAs (4 and 9 are the 16-cycle row-sum MFMAs)
+# what each of the ten MFMA gaps of a step takes, in order: e = next v_exp, c = next conversion (of v_exp two gaps back at the latest), l = next LDS
+# read, d = the step's LDS-DMA piece, b = the barrier group, s = two row-sum adds (lsum=valu).  Issue model (gen_attn_bwd_sp.py): a gap costs
+# max(MFMA time, fillers + ~5) with v_exp 8, plain VALU 5, an LDS instruction 9: [e e l] = 25 + 5, [e e c c] = 26 + 5 fill a 32-cycle gap.
+PATTERN2 = {0: OPTS.get('pat2', 'ee-eec-eec-eec-d-eec-eec-eec-eec-c').split('-'),
+            3: OPTS.get('pat23', 'eeb-eec-eec-eec-d-eec-eec-eec-eec-c').split('-')}
+PATTERN = {0: OPTS.get('pat', 'eel-eecl-eel-eecc-l-eel-eecc-eel-eecc-cd').split('-'),
+           3: OPTS.get('pat3', 'eeb-eecl-eel-eeccl-l-eel-eeccl-eel-eeccl-cd').split('-')}
+
+
+def step(k, pos, has_exp, has_pv, tail=False, last_body=False, cm=None, addr_cur=None, addr_next=None, dma=True, tag_t=0):
+    """one pipeline step = quarter k = 4 t + j.  pos = ring slot of tile t.  Returns (mfmas[10], gaps[10])"""
+    j = k & 3
+    mf = [mfma_qk(k, 0, cm), None, mfma_qk(k, 1), None, None, mfma_qk(k, 2), None, mfma_qk(k, 3), None, None]
+    if has_pv:
+        mf[1], mf[3], mf[4] = mfma_pv(k - 2, 0, 0), mfma_pv(k - 2, 0, 1), mfma_l(k - 2, 0)
+        mf[6], mf[8], mf[9] = mfma_pv(k - 2, 1, 0), mfma_pv(k - 2, 1, 1), mfma_l(k - 2, 1)
+    if 'lsum' in FDROP or LSUM_VALU:
+        mf[4] = mf[9] = None
+    gaps = [[] for _ in range(10)]
+    exps = [v_exp(k - 1, r) for r in range(16)] if (has_exp and 'exp' not in FDROP) else []
+    cvts = [v_cvt(k - 1, p) for p in range(8)] if (has_exp and 'cvt' not in FDROP) else []
+    sums = [v_sum(k - 1, r) for r in range(16)] if (has_exp and LSUM_VALU and 'lsum' not in FDROP) else []
+    # ---- LDS reads of this step, in issue order (see the header), the barrier group (step 4 t + 3) and the step's LDS-DMA piece
+    T_ = tag_t
+    lds, bar, piece = [], [], []
+    if j == 0:
+        lds = read_k(addr_cur, 1, 1, 0, (T_, 'K1')) + read_k(addr_cur, 1, 1, 1, (T_, 'K1')) + read_v(addr_cur, 0, 0, 0, (T_, 'V0')) + read_v(addr_cur, 0, 0, 1, (T_, 'V0'))
+    elif j == 1:
+        lds = read_k(addr_cur, 1, 1, 2, (T_, 'K1')) + read_k(addr_cur, 1, 1, 3, (T_, 'K1')) + read_v(addr_cur, 0, 1, 0, (T_, 'V0')) + read_v(addr_cur, 0, 1, 1, (T_, 'V0'))
+    elif j == 2:
+        lds = read_v(addr_cur, 1, 0, 0, (T_, 'V1')) + read_v(addr_cur, 1, 0, 1, (T_, 'V1'))
+    else:
+        if not tail:
+            # BARRIER(t + 1): this wave's pieces of tile t + 1 have landed (the three of tile t + 2 issued so far stay in flight)
+            bar = [I('s_waitcnt vmcnt(3)', 'vmwait'), I('s_barrier', 'barrier')]
+            for ks in range(4):
+                lds += read_k(addr_next, 0, 0, ks, (T_ + 1, 'K0'))
+        lds += read_v(addr_cur, 1, 1, 0, (T_, 'V1')) + read_v(addr_cur, 1, 1, 1, (T_, 'V1'))
+    if dma and not tail:
+        piece = dma_piece((pos + 2) % RING, j, None)
+    fixed = {}
+    if OCC2:
+        # single fragment sets: every register is re-read right behind its last use (odd steps: query block 1 has used it too), ten MFMAs ahead of
+        # its next use; K of the next key half behind the QK MFMAs, V^T of the key half after next behind the PV MFMAs
+        lds = []
+        if j & 1:
+            if j == 1:
+                for ks, g in enumerate((0, 2, 5, 7)):
+                    fixed[g] = read_k(addr_cur, 1, 1, ks, (T_, 'K1'))
+            elif not tail:
+                for ks, g in enumerate((0, 2, 5, 7)):
+                    fixed[g] = read_k(addr_next, 0, 0, ks, (T_ + 1, 'K0'))
+            for f, g in enumerate((1, 3, 6, 8)):
+                fixed[g] = read_v(addr_cur, j >> 1, f >> 1, f & 1, (T_, f'V{j >> 1}'))
+    pat = PATTERN2[3 if (j == 3 and not tail) else 0] if OCC2 else PATTERN[3 if (j == 3 and not tail) else 0]
+    done_e = 0
+    for g in range(10):
+        e_before = done_e
+        for ch in pat[g]:
+            if ch == 'e' and exps:
+                gaps[g].append(exps.pop(0))
+                done_e += 1
+            elif ch == 'c' and cvts:
+                assert not has_exp or 'exp' in FDROP or 2 * (8 - len(cvts)) + 2 <= e_before, 'a conversion in the gap of its own v_exp'
+                gaps[g].append(cvts.pop(0))
+            elif ch == 's' and sums:
+                gaps[g] += [sums.pop(0), sums.pop(0)]
+            elif ch == 'l' and lds:
+                gaps[g].append(lds.pop(0))
+            elif ch == 'd' and piece:
+                gaps[g] += piece
+                piece = []
+            elif ch == 'b' and bar:
+                gaps[g] += bar
+                bar = []
+        gaps[g] += fixed.get(g, [])
+    assert not exps and not cvts and not bar, (len(exps), len(cvts), len(bar))
+    gaps[9] += lds + piece + sums
+    return mf, gaps
+
+
+def emit_step(E, mf, gaps):
+    for m in range(10):
+        if mf[m] is not None:
+            E(mf[m])
+        for ins in gaps[m]:
+            E(ins)
+
+
+def mask_tuple(E, k, buf):
+    """tail: the seed tuple of quarter k with -inf where the key (32 kh + row of register r, + 4 hh: folded into limlane) lies past the end"""
+    j = k & 3
+    kh, qb = j >> 1, j & 1
+    b = SB(k) if OCC2 else V_CM + 16 * buf      # two-waves form: straight into the S set of the quarter (the chain then starts from its own destination)
+    for r in range(16):
+        row = 32 * kh + (r & 3) + 8 * (r >> 2)
+        E(I(f'v_cmp_lt_i32 vcc, {row}, {op("limlane")}', 'valu'))
+        E(I(f'v_cndmask_b32 v{b + r}, {op("neginf")}, {op(f"negm{qb}")}, vcc', 'valu', writes={f'v{b + r}'}))
+    E(I('s_nop 1', 'nop'))
+    return b
+
+
+def generate(occ2=False):
+    set_map(occ2)
+    H = Hazards()
+    H.OLD = 8
+    E = H.emit
+    # ---- entry: tiles 0 and 1 are in flight / landed (the wrapper waited for tile 0 behind a barrier to take the row maxima), s_koff / s_voff point at tile 2
+    a0 = Addr(0)
+    for ks in range(4):
+        for ins in read_k(a0, 0, 0, ks, (0, 'K0')):
+            E(ins)
+
+    def body(t_tag, pos, first):
+        cur, nxt = Addr(pos), Addr((pos + 1) % RING)
+        for j in range(4):
+            k = 4 * t_tag + j
+            has_exp = not (first and j == 0)
+            has_pv = not (first and j < 2)
+            mf, gaps = step(k, pos, has_exp, has_pv, addr_cur=cur, addr_next=nxt, tag_t=t_tag)
+            emit_step(E, mf, gaps)
+        E(I(f's_sub_u32 {op("s_cnt")}, {op("s_cnt")}, 1', 'salu'))
+        E(I(f's_mov_b32 {op("s_slot")}, {((pos + 1) % RING) * SLOT}', 'salu'))
+        E(I(f's_cmp_eq_u32 {op("s_cnt")}, 0', 'salu'))
+        E(I('s_cbranch_scc1 TAIL%=', 'branch'))
+
+    H.in_loop = True
+    body(0, 0, True)
+    s1 = H.state(0)
+    H.out.append(I('LOOP%=:', 'label'))
+    for n, pos in enumerate((1, 2, 3, 0)):
+        body(1 + n, pos, False)
+    assert H.state(RING) == s1, 'loop-carried LDS state differs'
+    E(I('s_branch LOOP%=', 'branch'))
+    H.in_loop = False
+    # ---- tail: the last tile (slot in s_slot) with masked seeds, then the drain of the pipeline.  Entered from any ring position with the SAME pending
+    # LDS reads (K[kh0] of the last tile), which the state assertion above guarantees.
+    H.out.append(I('TAIL%=:', 'label'))
+    names = [f'akr{ks}' for ks in range(4)] + [f'avt{db}{h}' for db in range(2) for h in range(2)]
+    for n, nm in enumerate(names):
+        E(I(f'v_add_u32 v{V_TA + n}, {op("s_slot")}, {op(nm)}', 'valu', writes={f'v{V_TA + n}'}))
+    ta = Addr(None)
+    T = 8            # tag only: any tile number whose quarter parity matches (4 T + j)
+    for j in range(4):
+        k = 4 * T + j
+        cm = mask_tuple(E, k, j & 1)
+        mf, gaps = step(k, 0, True, True, tail=True, cm=cm, addr_cur=ta, tag_t=T)
+        emit_step(E, mf, gaps)
+    for j in range(2):     # drain: exp / cvt of the last quarter, PV / L of the last two
+        k = 4 * T + 4 + j
+        mf = [None] * 10
+        mf[1], mf[3], mf[4] = mfma_pv(k - 2, 0, 0), mfma_pv(k - 2, 0, 1), mfma_l(k - 2, 0)
+        mf[6], mf[8], mf[9] = mfma_pv(k - 2, 1, 0), mfma_pv(k - 2, 1, 1), mfma_l(k - 2, 1)
+        if LSUM_VALU:
+            mf[4] = mf[9] = None
+        gaps = [[] for _ in range(10)]
+        if j == 0:
+            for r in range(16):
+                gaps[0].append(v_exp(k - 1, r))
+            for p in range(8):
+                gaps[0].append(v_cvt(k - 1, p))
+            if LSUM_VALU:
+                for r in range(16):
+                    gaps[0].append(v_sum(k - 1, r))
+            gaps[0].append(I('s_nop 1', 'nop'))
+        emit_step(E, mf, gaps)
+    H.drain('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    H.out.append(I('s_nop 7\n\ts_nop 7', 'nop'))
+    if 'lgkwait' in FDROP:      # timing-only: LDS reads without their waits
+        return [i for i in H.out[:-2] if not (i.kind == 'wait' and 'lgkmcnt' in i.text)] + H.out[-2:]
+    return H.out
+
+
+def render(stream, occ2=False):
+    lines = []
+    for ins in stream:
+        lines += ins.text.split('\n\t')
+    body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
+    outs = ', '.join(f'"+{{a[{AO(qb, db)}:{AO(qb, db) + 15}]}}"(o{qb}{db})' for qb in range(2) for db in range(2)) + ',\n      ' + \
+        (', '.join(f'[ps{qb}{c}] "+v"(ps{qb}{c})' for qb in range(2) for c in range(2)) if LSUM_VALU else
+         ', '.join(f'"+{{a[{AL(qb)}:{AL(qb) + 3}]}}"(lsum{qb})' for qb in range(2))) + ',\n      ' + \
+        ', '.join(f'[{n}] "+&s"({n})' for n in ('s_koff', 's_voff', 's_cnt')) + ', [s_t] "=&s"(s_t), [s_slot] "=&s"(s_slot)'
+    vin = [f'q{qb}{ks}' for qb in range(2) for ks in range(4)] + ['seed0', 'seed1', 'ones'] + [f'akr{ks}' for ks in range(4)] + \
+        [f'avt{db}{h}' for db in range(2) for h in range(2)] + ['voffK', 'voffV', 'limlane', 'negm0', 'negm1', 'neginf']
+    sin = ['srdK', 'srdV', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
+    acc_ops = {f'q{qb}{ks}' for qb in range(2) for ks in range(4)} | {'seed0', 'seed1', 'ones'} if occ2 else set()      # two-waves form: MFMA-only operands live in the accumulator half
+    ins_ = ', '.join(f'[{n}] "{"a" if n in acc_ops else "v"}"({n})' for n in vin) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
+    clob = ', '.join(f'"v{i}"' for i in range(64 if FRAG_ACC else 0, N_HAND)) + (', ' + ', '.join(f'"a{i}"' for i in range(72, 136)) if FRAG_ACC else '') + ', "vcc", "scc", "memory"'
+    return ('// GENERATED by gen_attn_fwd4w.py -- do not edit; see that file for the register map and the schedule\n' +
+            '#undef F4W_LSUM_VALU\n' + ('#define F4W_LSUM_VALU 1\n' if LSUM_VALU else '#define F4W_LSUM_VALU 0\n') +
+            'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
+
+
+FILES = ['attn_fwd4w_body.inc', 'attn_fwd2x_body.inc']
+
+
+def generate_all(outdir):
+    for name, occ2 in zip(FILES, (False, True)):
+        stream = generate(occ2)
+        with open(os.path.join(outdir, name), 'w') as f:
+            f.write(render(stream, occ2))
+        yield name, stream
+
+
+if __name__ == '__main__':
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, stream in generate_all(here):
+        if '-v' in sys.argv:
+            kinds = {}
+            for ins in stream:
+                kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+            print(name, kinds)

@@ -48,6 +48,7 @@ SIGNATURES = {
     'crl_attn_bwd': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, L, L, P, P, P, L, L, P, L, L, P, L, L,
                          I, I, I, I, F, I, I, F, U64, U32, U32, P, Z, P]),
     'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
+    'crl_attn_fwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),
     'crl_attn_bwd_set_chain': (I, [I]),

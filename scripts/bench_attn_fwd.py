@@ -1,0 +1,62 @@
+"""forward attention, hand-placed stream (crl_attn_fwd_set_mode 0) against the compiler-scheduled kernel (mode 1), alternating on one box.
+    python scripts/bench_attn_fwd.py [lib.so ...]      # extra libraries = timing-only variants of the stream (scripts/ab_f4w.sh)"""
+import os
+import sys
+import time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from pixparse_amd import hip, ops
+    hip.load()
+    dev = torch.device('cuda:0')
+    lib = hip.load()
+    stamps = None
+    if hasattr(lib, 'crl_debug_f4w_stamps'):      # diagnostic builds: cycles of the stream statement per workgroup
+        import ctypes
+        stamps = torch.zeros(8 * 16 * 25, dtype=torch.int64, device=dev)
+        lib.crl_debug_f4w_stamps.argtypes = [ctypes.c_void_p]
+        lib.crl_debug_f4w_stamps(stamps.data_ptr())
+    shapes = [('vit', 8, 16, 6189, 6189), ('cross', 8, 16, 1023, 6189)]
+    one = 'one' in sys.argv
+    if one:
+        shapes = shapes[:1]
+    for name, B, H, Nq, Nk in shapes:
+        D = H * 64
+        g = torch.Generator(device=dev).manual_seed(1)
+        qkv = torch.randn(B, max(Nq, Nk), 3 * D, generator=g, device=dev).to(torch.bfloat16)
+        q, k, v = qkv[:, :Nq, :D], qkv[:, :Nk, D:2 * D], qkv[:, :Nk, 2 * D:]
+        qp = (q.float() * 0.125 * ops.LOG2E).to(torch.bfloat16)
+        o = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(B, H, Nq, device=dev)
+        fl = 4.0 * Nq * Nk * 64 * B * H
+        ref = None
+        for rnd in range(1 if one else 3):
+            for mode in ((0,) if one else (1, 0)):
+                hip.call('crl_attn_fwd_set_mode', mode)
+                for _ in range(5):
+                    ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 40
+                e0.record()
+                for _ in range(n):
+                    ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / n
+                extra = ''
+                if mode == 1:
+                    ref = o.clone()
+                elif ref is not None:
+                    extra = f'  rel diff vs mode 1: {float((o.float() - ref.float()).norm() / ref.float().norm()):.2e}'
+                if stamps is not None and mode == 0 and name == 'vit':
+                    st = stamps[:B * H * ((Nq + 255) // 256)].float()
+                    extra += f'  stream cycles per workgroup: mean {float(st.mean()):.0f} min {float(st.min()):.0f} max {float(st.max()):.0f} = {float(st.mean()) / ((Nk + 63) // 64):.0f} per key tile'
+                print(f'{name:6s} B{B} H{H} Nq{Nq} Nk{Nk} round {rnd} {"stream (4 waves x 64 q)" if mode == 0 else "32 q per wave        "}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s{extra}', flush=True)
+        hip.call('crl_attn_fwd_set_mode', 0)
+
+
+if __name__ == '__main__':
+    main()

@@ -85,6 +85,77 @@ def test_attention_q_prescaled(dev, B, H, Nq, Nk, causal):
             assert rel(o, o2) < 2e-2
 
 
+@pytest.mark.parametrize('B,H,Nq,Nk', [(1, 2, 200, 333), (1, 1, 64, 128), (2, 8, 700, 1000), (1, 2, 1023, 1300), (1, 1, 45, 6189), (1, 3, 513, 192), (1, 2, 256, 2049)])
+def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
+    """the hand-placed forward stream (crl_attn_fwd_set_mode 0: 256 queries per workgroup, fixed first-tile reference, row sums on the matrix
+    pipe, masked last key tile) against fp32 torch and against the compiler-scheduled kernel (mode 1) on ragged Nq / Nk; mode 2 (every block
+    re-run by its moving-maximum fallback) must reproduce mode 1 bit for bit; twice the same bits"""
+    from pixparse_amd import hip, ops
+    D = H * 64
+    c = 0.125 * ops.LOG2E
+    g = torch.Generator(device=dev).manual_seed(Nq * 7 + Nk)
+    qpre = (torch.randn(B, Nq, D, generator=g, device=dev) * c * 2.0).to(BF16)
+    k = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+    v = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+    res = {}
+    try:
+        for mode in (0, 1, 2, 0):
+            hip.call('crl_attn_fwd_set_mode', mode)
+            o = torch.full_like(qpre, float('nan'))
+            lse = torch.full((B, H, Nq), float('nan'), device=dev)
+            ops.attn_fwd(qpre, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+            if mode in res:
+                assert torch.equal(res[mode][0], o) and torch.equal(res[mode][1], lse), 'not reproducible'
+            res[mode] = (o, lse)
+    finally:
+        hip.call('crl_attn_fwd_set_mode', 0)
+    hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    z = hd(qpre) @ hd(k).transpose(-1, -2) * math.log(2.0)
+    ref = (torch.softmax(z, -1) @ hd(v)).transpose(1, 2).reshape(B, Nq, D)
+    lref = torch.logsumexp(z, -1)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1]), 'fallback differs from the compiler-scheduled kernel'
+    assert rel(res[0][0], ref) < 1e-2 and rel(res[1][0], ref) < 1e-2, (rel(res[0][0], ref), rel(res[1][0], ref))
+    # lse: the stream sums the bf16-ROUNDED probabilities (the operand of P.V, on the matrix pipe): a row dominated by one key carries that key's
+    # rounding, half a bf16 ulp = 2^-8 = 3.9e-3 relative in l at most; the normalised weights of the output sum to one exactly
+    assert float((res[0][1] - lref).abs().max()) < 5e-3, float((res[0][1] - lref).abs().max())
+    assert float((res[1][1] - lref).abs().max()) < 3e-3, float((res[1][1] - lref).abs().max())
+    close(res[0][0], ref, 2e-2, 2e-2, 'stream out')
+
+
+def test_attention_fwd_stream_overflow_falls_back(dev):
+    """rows whose later scores exceed the first key tile's maximum by more than 2^127 (and rows that stay far below it) -- the stream's fixed
+    reference overflows, the workgroup re-runs the block with the moving maximum: finite and right; moderate growth (2^60) stays in line"""
+    from pixparse_amd import hip, ops
+    B, H, Nq, Nk = 1, 2, 300, 640
+    D = H * 64
+    for amp, must_equal_mode1 in ((40.0, False), (400.0, True)):
+        g = torch.Generator(device=dev).manual_seed(int(amp))
+        q = torch.randn(B, Nq, D, generator=g, device=dev).abs()
+        k = torch.randn(B, Nk, D, generator=g, device=dev).abs() * torch.linspace(0.05, 1.0, Nk, device=dev).view(1, Nk, 1)
+        qpre = (q * (amp / 64.0)).to(BF16)              # base-2 logits grow to ~amp along the keys
+        k = k.to(BF16)
+        v = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+        outs = []
+        try:
+            for mode in (0, 1):
+                hip.call('crl_attn_fwd_set_mode', mode)
+                o = torch.full_like(qpre, float('nan'))
+                lse = torch.full((B, H, Nq), float('nan'), device=dev)
+                ops.attn_fwd(qpre, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+                outs.append((o, lse))
+        finally:
+            hip.call('crl_attn_fwd_set_mode', 0)
+        hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2)
+        z = hd(qpre) @ hd(k).transpose(-1, -2) * math.log(2.0)
+        ref = (torch.softmax(z, -1) @ hd(v)).transpose(1, 2).reshape(B, Nq, D)
+        assert torch.isfinite(outs[0][0].float()).all() and torch.isfinite(outs[0][1]).all()
+        close(outs[0][0], ref, 2e-2, 2e-2, f'overflowing stream out, amp {amp}')
+        assert float((outs[0][1] - torch.logsumexp(z, -1)).abs().max()) < 5e-3 * max(1.0, float(z.abs().max()) / 50)
+        if must_equal_mode1:
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_gemm_column_scale(dev):
     """crl_gemm_bf16 colscale: the first colscale_cols columns of the plain bf16 epilogue are multiplied before the rounding -- through
     the 256x256 kernel, the 128x128 kernel, the remainder rows and the split-contraction reduce"""
