@@ -181,10 +181,13 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
  * crl_attn_bwd_set_mode: 0 = auto: single pass for non-causal problems with Nq >= 1000, Nk >= 1024 and a prescaled q (the ViT encoders:
  *   same-box 3.22 against 3.51 ms per layer at B 8, H 16, N 6189; cross-attention 1023 x 6189: 0.63 against 0.67), two-pass otherwise; 1 = two-pass; 2 = single pass whenever legal
  *   (non-causal); 3 = single pass in its C++ form (reference of the hand-placed stream: bit-identical results). */
-/* crl_attn_fwd with q_prescaled, no causal mask, no dropout and Nk >= 128 runs a hand-placed one-wave-per-SIMD instruction stream
- * (csrc/gen_attn_fwd4w.py: 256 queries per workgroup, 64 per wave; the softmax reference of a row is its exact maximum over the first key
- * tile; a block with a non-finite row is re-run with the moving-maximum kernel).  crl_attn_fwd_set_mode: 0 = auto (default), 1 = the
- * 32-queries-per-wave kernels everywhere, 2 = the stream with its fallback forced on every block (tests). */
+/* crl_attn_fwd with q_prescaled, no causal mask, no dropout and Nk >= 128 runs a hand-placed instruction stream (csrc/gen_attn_fwd4w.py:
+ * 256 queries per workgroup, 64 per wave, so that every K / V fragment read from LDS feeds two MFMAs; software pipeline over quarter tiles; row
+ * sums of the bf16 probabilities on the matrix pipe; the softmax reference of a row is its exact maximum over the first key tile; a block with
+ * a non-finite row is re-run with the moving-maximum kernel).  Two register budgets of the same pipeline: 256 registers per wave = two
+ * workgroups per CU (default: two waves per SIMD overlap each other's v_exp / LDS / MFMA issue and the stream runs at the matrix pipe's rate)
+ * and 512 = one per CU.  crl_attn_fwd_set_mode: 0 = auto (default), 1 = the 32-queries-per-wave kernels everywhere, 2 = the stream with its
+ * fallback forced on every block (tests), 3 = the 512-register form, 4 = the 256-register form. */
 int crl_attn_fwd_set_mode(int mode);
 size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
 int crl_attn_bwd_set_mode(int mode);

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_pre_kernel(const AttnArgs a) 
 #define F4W_STAMPS 0
 #endif
 #ifndef F4W_OCC2
-#define F4W_OCC2 0      // 1: also build the two-waves-per-SIMD form (experimental: see DESIGN.md)
+#define F4W_OCC2 1      // 0: build without the two-waves-per-SIMD form (its register budget is exact: 128 + 128 under LLVM's even split at 2 waves per SIMD)
 #endif
 constexpr int F4W_LDS = 4 * 16384;
 #if F4W_STAMPS      // diagnostic builds (scripts/ab_f4w.sh): cycles of the stream statement per workgroup (wave 0), s_memtime
@@ -511,22 +511,27 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
   f32x4 lsum0 = f32x4{0.f, 0.f, 0.f, 0.f}, lsum1 = f32x4{0.f, 0.f, 0.f, 0.f};      // row sums on the matrix pipe ...
   float ps00 = 0.f, ps01 = 0.f, ps10 = 0.f, ps11 = 0.f;                              // ... or as VALU adds (generator option lsum=valu)
   {
-    const bf16x8 q00 = qf[0][0], q01 = qf[0][1], q02 = qf[0][2], q03 = qf[0][3], q10 = qf[1][0], q11 = qf[1][1], q12 = qf[1][2], q13 = qf[1][3];
-    const uint32_t akr0 = sbase + la.row[0], akr1 = sbase + la.row[1], akr2 = sbase + la.row[2], akr3 = sbase + la.row[3];
-    const uint32_t avt00 = sbase + la.tr[0][0], avt01 = sbase + la.tr[0][1], avt10 = sbase + la.tr[1][0], avt11 = sbase + la.tr[1][1];
-    const uint32_t voffK = sk.v, voffV = sv.v;
     const int limlane = (a.Nk - (nt - 1) * 64) - 4 * hh;      // last tile: key row 32 kh + (r & 3) + 8 (r >> 2) of this lane half is valid iff < limlane
+    const uint32_t voffK = sk.v, voffV = sv.v;
     const uint32_t s_ldsw = sbase + (uint32_t)wave * 1024u;
     const uint32_t s_k32 = (uint32_t)(32 * a.k_rs * 2), s_v32 = (uint32_t)(32 * a.v_rs * 2);
     const uint32_t s_kstep = (uint32_t)(64 * a.k_rs * 2), s_vstep = (uint32_t)(64 * a.v_rs * 2);
     uint32_t s_koff = 2u * s_kstep, s_voff = 2u * s_vstep, s_cnt = (uint32_t)(nt - 1), s_t, s_slot;
+    uint32_t akr0 = sbase + la.row[0], akr1 = sbase + la.row[1], akr2 = sbase + la.row[2], akr3 = sbase + la.row[3];
+    uint32_t avt00 = sbase + la.tr[0][0], avt01 = sbase + la.tr[0][1], avt10 = sbase + la.tr[1][0], avt11 = sbase + la.tr[1][1];
 #if F4W_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (OCC == 1) {
+      const bf16x8 q00 = qf[0][0], q01 = qf[0][1], q02 = qf[0][2], q03 = qf[0][3], q10 = qf[1][0], q11 = qf[1][1], q12 = qf[1][2], q13 = qf[1][3];
 #include "attn_fwd4w_body.inc"
     } else {
 #if F4W_OCC2
+      // the stream loads the Q fragments itself (into accumulator registers) and builds its seed / ONES tuples from one register each
+      const u32x4 srdQ = make_srd(qp, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
+      const uint32_t voffQ0 = (uint32_t)(((int64_t)min(q0 + qi, a.Nq - 1) * a.q_rs + 8 * hh) * 2);
+      const uint32_t voffQ1 = (uint32_t)(((int64_t)min(q0 + 32 + qi, a.Nq - 1) * a.q_rs + 8 * hh) * 2);
+      const uint32_t onesv = (((lane & 15) == 1 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 2 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
 #include "attn_fwd2x_body.inc"
 #endif
     }
@@ -1352,7 +1357,8 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
   CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
   if (q_prescaled && !drop && !causal && g_fwd_mode != 1 && Nk >= 128) {
-    // the one-wave-per-SIMD stream: 256 queries per workgroup (mode 2: every block also runs its moving-maximum fallback -- tests)
+    // the hand-placed stream: 256 queries per workgroup, two workgroups per CU (mode 3: the 512-register form, one per CU; mode 2: every block also
+    // runs its moving-maximum fallback -- tests)
     static bool configured = false;
     if (!configured) {
       for (const void* f : {reinterpret_cast<const void*>(&attn_fwd4w_kernel<1>), reinterpret_cast<const void*>(&attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1>)}) {
@@ -1362,8 +1368,8 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
       configured = true;
     }
     const unsigned g4 = (unsigned)((Nq + 255) / 256) * B * H;
-    if (g_fwd_mode == 4 && F4W_OCC2) attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, 0);
-    else attn_fwd4w_kernel<1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
+    if (g_fwd_mode == 3 || !F4W_OCC2) attn_fwd4w_kernel<1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
+    else attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
   } else if (q_prescaled) {       // base-2 logits straight from the MFMAs: the seeded / lazy-maximum kernel (`scale` is not used)
     if (drop) { if (causal) attn_fwd_pre_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a); else attn_fwd_pre_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a); }
     else if (causal) attn_fwd_pre_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);

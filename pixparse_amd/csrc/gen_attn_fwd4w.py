@@ -58,7 +58,7 @@ def set_map(occ2):
     global OCC2, V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND
     OCC2 = occ2
     if occ2:
-        V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = 0, 16, 32, 64, None, 80, 88
+        V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = 0, A_VF2, 16, 48, None, None, 96
     else:
         V_KF, V_VF, V_S, V_P, V_CM, V_TA, N_HAND = (72 if FRAG_ACC else 0), (104 if FRAG_ACC else 32), 64, 96, 112, 144, 152
 RING = 4
@@ -93,12 +93,15 @@ def vt(b, n):
     return f'v[{b}:{b + n - 1}]'
 
 
-def ft(b, n):
-    return f'{FP}[{b}:{b + n - 1}]'
+def ft(b, n, which='k'):
+    """fragment registers: K ('k') / V^T ('v') sets; the two-waves form keeps V^T in the accumulator half (LLVM splits a 256-register budget 128 + 128)"""
+    pre = ('a' if which == 'v' else 'v') if OCC2 else FP
+    return f'{pre}[{b}:{b + n - 1}]'
 
 
-def fregs(b, n):
-    return {f'{FP}{i}' for i in range(b, b + n)}
+def fregs(b, n, which='k'):
+    pre = ('a' if which == 'v' else 'v') if OCC2 else FP
+    return {f'{pre}{i}' for i in range(b, b + n)}
 
 
 def at(b, n):
@@ -106,17 +109,33 @@ def at(b, n):
 
 
 # ---------------------------------------------------------------------------------------------------------------- instruction builders
+A_Q, A_ONES, A_VF2, A_END = 72, 104, 108, 124      # two-waves form: Q fragments, ONES and the V^T fragment set in hand-allocated accumulator registers
+V_SEED2 = 64                           # ... its seed tuples (C and D of an MFMA share a register file: S is exponentiated by the VALU) v[64:95]
+
+
+def q_op(qb, ks):
+    return at(A_Q + 16 * qb + 4 * ks, 4) if OCC2 else op(f'q{qb}{ks}')
+
+
+def seed_op(qb):
+    return vt(V_SEED2 + 16 * qb, 16) if OCC2 else op(f'seed{qb}')
+
+
+def ones_op():
+    return at(A_ONES, 4) if OCC2 else op('ones')
+
+
 def mfma_qk(k, ks, cm=None):
     """S[k & 1] (+)= K[kh][ks] . Q[qb][ks]^T; the chain starts from the seed tuple of the query block (or the masked tuple `cm`, tail)"""
     j = k & 3
     kh, qb = j >> 1, j & 1
     d = SB(k)
     if ks == 0:
-        c = vt(cm, 16) if cm is not None else op(f'seed{qb}')
+        c = vt(cm, 16) if cm is not None else seed_op(qb)
     else:
         c = vt(d, 16)
     rd = fregs(KF(kh, ks), 4) | (vregs(cm, 16) if (cm is not None and ks == 0) else set())
-    return I(f'v_mfma_f32_32x32x16_bf16 {vt(d, 16)}, {ft(KF(kh, ks), 4)}, {op(f"q{qb}{ks}")}, {c}', 'mfma', reads=rd, writes=vregs(d, 16))
+    return I(f'v_mfma_f32_32x32x16_bf16 {vt(d, 16)}, {ft(KF(kh, ks), 4)}, {q_op(qb, ks)}, {c}', 'mfma', reads=rd, writes=vregs(d, 16))
 
 
 def mfma_pv(k, s, db):
@@ -124,13 +143,13 @@ def mfma_pv(k, s, db):
     j = k & 3
     kh, qb = j >> 1, j & 1
     o = AO(qb, db)
-    return I(f'v_mfma_f32_32x32x16_bf16 {at(o, 16)}, {ft(VF(kh, 2 * s + db), 4)}, {vt(PB(k, s), 4)}, {at(o, 16)}', 'mfma',
-             reads=fregs(VF(kh, 2 * s + db), 4) | vregs(PB(k, s), 4))
+    return I(f'v_mfma_f32_32x32x16_bf16 {at(o, 16)}, {ft(VF(kh, 2 * s + db), 4, "v")}, {vt(PB(k, s), 4)}, {at(o, 16)}', 'mfma',
+             reads=fregs(VF(kh, 2 * s + db), 4, 'v') | vregs(PB(k, s), 4))
 
 
 def mfma_l(k, s):
     qb = k & 1
-    return I(f'v_mfma_f32_16x16x32_bf16 {at(AL(qb), 4)}, {op("ones")}, {vt(PB(k, s), 4)}, {at(AL(qb), 4)}', 'mfma', reads=vregs(PB(k, s), 4))
+    return I(f'v_mfma_f32_16x16x32_bf16 {at(AL(qb), 4)}, {ones_op()}, {vt(PB(k, s), 4)}, {at(AL(qb), 4)}', 'mfma', reads=vregs(PB(k, s), 4))
 
 
 def v_exp(k, r):
@@ -157,10 +176,14 @@ class Addr:
         self.slot = slot
 
     def k(self, ks):
-        return (op(f'akr{ks}'), self.slot * SLOT) if self.slot is not None else (f'v{V_TA + ks}', 0)
+        if self.slot is not None:
+            return op(f'akr{ks}'), self.slot * SLOT
+        return (op(f'akr{ks}'), 0) if OCC2 else (f'v{V_TA + ks}', 0)      # tail: the two-waves form advances the operands themselves
 
     def v(self, db, half):
-        return (op(f'avt{db}{half}'), self.slot * SLOT) if self.slot is not None else (f'v{V_TA + 4 + 2 * db + half}', 0)
+        if self.slot is not None:
+            return op(f'avt{db}{half}'), self.slot * SLOT
+        return (op(f'avt{db}{half}'), 0) if OCC2 else (f'v{V_TA + 4 + 2 * db + half}', 0)
 
 
 def read_k(addr, kh_src, kh_dst, ks, tag):
@@ -174,7 +197,7 @@ def read_v(addr, kh, s, db, tag):
     out = []
     for half in range(2):
         reg, imm = addr.v(db, half)
-        out.append(I(f'ds_read_b64_tr_b16 {ft(b + 2 * half, 2)}, {reg} offset:{imm + 8192 + 4096 * kh + 2048 * s}', 'ds', writes=fregs(b + 2 * half, 2), tag=tag))
+        out.append(I(f'ds_read_b64_tr_b16 {ft(b + 2 * half, 2, "v")}, {reg} offset:{imm + 8192 + 4096 * kh + 2048 * s}', 'ds', writes=fregs(b + 2 * half, 2, 'v'), tag=tag))
     return out
 
 
@@ -292,7 +315,11 @@ def mask_tuple(E, k, buf):
     for r in range(16):
         row = 32 * kh + (r & 3) + 8 * (r >> 2)
         E(I(f'v_cmp_lt_i32 vcc, {row}, {op("limlane")}', 'valu'))
-        E(I(f'v_cndmask_b32 v{b + r}, {op("neginf")}, {op(f"negm{qb}")}, vcc', 'valu', writes={f'v{b + r}'}))
+        if OCC2:
+            E(I(f'v_mov_b32 v{b + r}, 0xff800000', 'valu', writes={f'v{b + r}'}))
+            E(I(f'v_cndmask_b32 v{b + r}, v{b + r}, {op(f"negm{qb}")}, vcc', 'valu', writes={f'v{b + r}'}))
+        else:
+            E(I(f'v_cndmask_b32 v{b + r}, {op("neginf")}, {op(f"negm{qb}")}, vcc', 'valu', writes={f'v{b + r}'}))
     E(I('s_nop 1', 'nop'))
     return b
 
@@ -304,9 +331,23 @@ def generate(occ2=False):
     E = H.emit
     # ---- entry: tiles 0 and 1 are in flight / landed (the wrapper waited for tile 0 behind a barrier to take the row maxima), s_koff / s_voff point at tile 2
     a0 = Addr(0)
+    if occ2:
+        # Q fragments straight from memory into the accumulator half (8 x 16 bytes per lane; the wrapper's own copy died with the row maxima), seeds and
+        # ONES written there from one register each: the statement has no register-tuple operands left
+        for qb in range(2):
+            for ks in range(4):
+                E(I(f'buffer_load_dwordx4 {at(A_Q + 16 * qb + 4 * ks, 4)}, {op(f"voffQ{qb}")}, {op("srdQ")}, 0 offen offset:{32 * ks}', 'vmem'))
+        for qb in range(2):
+            for r in range(16):
+                E(I(f'v_mov_b32 v{V_SEED2 + 16 * qb + r}, {op(f"negm{qb}")}', 'valu'))
+        for r in range(4):
+            E(I(f'v_accvgpr_write_b32 a{A_ONES + r}, {op("onesv")}', 'valu'))
     for ks in range(4):
         for ins in read_k(a0, 0, 0, ks, (0, 'K0')):
             E(ins)
+    if occ2:
+        H.out.append(I('s_waitcnt vmcnt(0)', 'wait'))      # Q (and with it tile 1: the queue retires in order)
+        H.out.append(I('s_nop 1', 'nop'))
 
     def body(t_tag, pos, first):
         cur, nxt = Addr(pos), Addr((pos + 1) % RING)
@@ -335,7 +376,10 @@ def generate(occ2=False):
     H.out.append(I('TAIL%=:', 'label'))
     names = [f'akr{ks}' for ks in range(4)] + [f'avt{db}{h}' for db in range(2) for h in range(2)]
     for n, nm in enumerate(names):
-        E(I(f'v_add_u32 v{V_TA + n}, {op("s_slot")}, {op(nm)}', 'valu', writes={f'v{V_TA + n}'}))
+        if OCC2:
+            E(I(f'v_add_u32 {op(nm)}, {op("s_slot")}, {op(nm)}', 'valu'))
+        else:
+            E(I(f'v_add_u32 v{V_TA + n}, {op("s_slot")}, {op(nm)}', 'valu', writes={f'v{V_TA + n}'}))
     ta = Addr(None)
     T = 8            # tag only: any tile number whose quarter parity matches (4 T + j)
     for j in range(4):
@@ -373,16 +417,22 @@ def render(stream, occ2=False):
     for ins in stream:
         lines += ins.text.split('\n\t')
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
+    addr_names = [f'akr{ks}' for ks in range(4)] + [f'avt{db}{h}' for db in range(2) for h in range(2)]
     outs = ', '.join(f'"+{{a[{AO(qb, db)}:{AO(qb, db) + 15}]}}"(o{qb}{db})' for qb in range(2) for db in range(2)) + ',\n      ' + \
         (', '.join(f'[ps{qb}{c}] "+v"(ps{qb}{c})' for qb in range(2) for c in range(2)) if LSUM_VALU else
          ', '.join(f'"+{{a[{AL(qb)}:{AL(qb) + 3}]}}"(lsum{qb})' for qb in range(2))) + ',\n      ' + \
-        ', '.join(f'[{n}] "+&s"({n})' for n in ('s_koff', 's_voff', 's_cnt')) + ', [s_t] "=&s"(s_t), [s_slot] "=&s"(s_slot)'
-    vin = [f'q{qb}{ks}' for qb in range(2) for ks in range(4)] + ['seed0', 'seed1', 'ones'] + [f'akr{ks}' for ks in range(4)] + \
-        [f'avt{db}{h}' for db in range(2) for h in range(2)] + ['voffK', 'voffV', 'limlane', 'negm0', 'negm1', 'neginf']
-    sin = ['srdK', 'srdV', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
-    acc_ops = {f'q{qb}{ks}' for qb in range(2) for ks in range(4)} | {'seed0', 'seed1', 'ones'} if occ2 else set()      # two-waves form: MFMA-only operands live in the accumulator half
-    ins_ = ', '.join(f'[{n}] "{"a" if n in acc_ops else "v"}"({n})' for n in vin) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
-    clob = ', '.join(f'"v{i}"' for i in range(64 if FRAG_ACC else 0, N_HAND)) + (', ' + ', '.join(f'"a{i}"' for i in range(72, 136)) if FRAG_ACC else '') + ', "vcc", "scc", "memory"'
+        ', '.join(f'[{n}] "+&s"({n})' for n in ('s_koff', 's_voff', 's_cnt')) + ', [s_t] "=&s"(s_t), [s_slot] "=&s"(s_slot)' + \
+        ((',\n      ' + ', '.join(f'[{n}] "+v"({n})' for n in addr_names)) if occ2 else '')
+    if occ2:
+        vin = ['voffK', 'voffV', 'voffQ0', 'voffQ1', 'limlane', 'negm0', 'negm1', 'onesv']
+        sin = ['srdK', 'srdV', 'srdQ', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
+    else:
+        vin = [f'q{qb}{ks}' for qb in range(2) for ks in range(4)] + ['seed0', 'seed1', 'ones'] + addr_names + ['voffK', 'voffV', 'limlane', 'negm0', 'negm1', 'neginf']
+        sin = ['srdK', 'srdV', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
+    ins_ = ', '.join(f'[{n}] "v"({n})' for n in vin) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
+    clob = ', '.join(f'"v{i}"' for i in range(64 if FRAG_ACC and not occ2 else 0, N_HAND)) + \
+        (', ' + ', '.join(f'"a{i}"' for i in range(72, 136)) if FRAG_ACC and not occ2 else '') + \
+        (', ' + ', '.join(f'"a{i}"' for i in range(A_Q, A_END)) if occ2 else '') + ', "vcc", "scc", "memory"'
     return ('// GENERATED by gen_attn_fwd4w.py -- do not edit; see that file for the register map and the schedule\n' +
             '#undef F4W_LSUM_VALU\n' + ('#define F4W_LSUM_VALU 1\n' if LSUM_VALU else '#define F4W_LSUM_VALU 0\n') +
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')

@@ -223,10 +223,19 @@ def _drop_args(drop, site):
 LOG2E = 1.4426950408889634
 
 
+_attn_fwd_env_applied = False
+
+
 def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool, drop=None, site: int = 0, q_prescaled: bool = False) -> None:
     """q [B,Nq,H*64], k/v [B,Nk,H*64] (strided views allowed), o like q, lse [B,H,Nq] f32.
     drop (DropSpec with p_attn > 0) + site: dropout of the attention probabilities (the backward call must pass the same pair).
     q_prescaled: q already carries scale * log2(e) (linear_fwd(..., colscale=scale * LOG2E, colscale_cols=D)): the faster forward kernel."""
+    global _attn_fwd_env_applied
+    if not _attn_fwd_env_applied:      # A/B switch: PIXPARSE_AMD_ATTN_FWD_MODE=1 the compiler-scheduled kernels, 3 / 4 the stream at one / two workgroups per CU
+        import os
+        _attn_fwd_env_applied = True
+        if os.environ.get('PIXPARSE_AMD_ATTN_FWD_MODE'):
+            hip.call('crl_attn_fwd_set_mode', int(os.environ['PIXPARSE_AMD_ATTN_FWD_MODE']))
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o)

@@ -10,7 +10,7 @@ FL=$(python -c "from pixparse_amd import build; print(' '.join(build.FLAGS + bui
 while [ $# -ge 2 ]; do
   name=$1; envs=$2; shift 2
   ( export $envs; cd $C && python gen_attn_fwd4w.py ) || exit 1
-  hipcc $FL -DF4W_NO_FALLBACK=1 -DF4W_STAMPS=1 -c $C/attention.hip -o /tmp/attention_$name.o || exit 1
+  hipcc $FL -DF4W_NO_FALLBACK=1 -DF4W_STAMPS=1 $F4W_CFLAGS -c $C/attention.hip -o /tmp/attention_$name.o || exit 1
   hipcc --offload-arch=gfx950 -shared -fPIC -o $C/variants/$name.so /tmp/attention_$name.o $(ls $C/*.o | grep -v attention.o | tr "\n" " ") || exit 1
   echo "built $name ($envs)"
 done

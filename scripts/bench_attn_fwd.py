@@ -7,6 +7,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+NAMES = {0: 'stream, 1 wave / SIMD  ', 1: '32 q per wave          ', 4: 'stream, 2 waves / SIMD '}
+
+
 def main():
     from pixparse_amd import hip, ops
     hip.load()
@@ -33,8 +36,10 @@ def main():
         fl = 4.0 * Nq * Nk * 64 * B * H
         ref = None
         for rnd in range(1 if one else 3):
-            for mode in ((0,) if one else (1, 0)):
+            for mode in ((0, 4) if one else (1, 0, 4)):
                 hip.call('crl_attn_fwd_set_mode', mode)
+                if mode == 4 and os.environ.get('F4W_OCC2', '0') != '1':
+                    continue
                 for _ in range(5):
                     ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
                 torch.cuda.synchronize()
@@ -51,10 +56,10 @@ def main():
                     ref = o.clone()
                 elif ref is not None:
                     extra = f'  rel diff vs mode 1: {float((o.float() - ref.float()).norm() / ref.float().norm()):.2e}'
-                if stamps is not None and mode == 0 and name == 'vit':
+                if stamps is not None and mode != 1 and name == 'vit':
                     st = stamps[:B * H * ((Nq + 255) // 256)].float()
                     extra += f'  stream cycles per workgroup: mean {float(st.mean()):.0f} min {float(st.min()):.0f} max {float(st.max()):.0f} = {float(st.mean()) / ((Nk + 63) // 64):.0f} per key tile'
-                print(f'{name:6s} B{B} H{H} Nq{Nq} Nk{Nk} round {rnd} {"stream (4 waves x 64 q)" if mode == 0 else "32 q per wave        "}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s{extra}', flush=True)
+                print(f'{name:6s} B{B} H{H} Nq{Nq} Nk{Nk} round {rnd} {NAMES[mode]}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s{extra}', flush=True)
         hip.call('crl_attn_fwd_set_mode', 0)
 
 

@@ -89,7 +89,7 @@ def test_attention_q_prescaled(dev, B, H, Nq, Nk, causal):
 def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
     """the hand-placed forward stream (crl_attn_fwd_set_mode 0: 256 queries per workgroup, fixed first-tile reference, row sums on the matrix
     pipe, masked last key tile) against fp32 torch and against the compiler-scheduled kernel (mode 1) on ragged Nq / Nk; mode 2 (every block
-    re-run by its moving-maximum fallback) must reproduce mode 1 bit for bit; twice the same bits"""
+    re-run by its moving-maximum fallback) must reproduce mode 1 bit for bit; twice the same bits; the one-workgroup-per-CU form (mode 3) the same bits"""
     from pixparse_amd import hip, ops
     D = H * 64
     c = 0.125 * ops.LOG2E
@@ -99,7 +99,7 @@ def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
     v = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
     res = {}
     try:
-        for mode in (0, 1, 2, 0):
+        for mode in (0, 1, 2, 0, 3):
             hip.call('crl_attn_fwd_set_mode', mode)
             o = torch.full_like(qpre, float('nan'))
             lse = torch.full((B, H, Nq), float('nan'), device=dev)
@@ -115,6 +115,7 @@ def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
     lref = torch.logsumexp(z, -1)
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
     assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1]), 'fallback differs from the compiler-scheduled kernel'
+    assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[3][1], res[0][1]), 'the 512-register form differs from the 256-register form'
     assert rel(res[0][0], ref) < 1e-2 and rel(res[1][0], ref) < 1e-2, (rel(res[0][0], ref), rel(res[1][0], ref))
     # lse: the stream sums the bf16-ROUNDED probabilities (the operand of P.V, on the matrix pipe): a row dominated by one key carries that key's
     # rounding, half a bf16 ulp = 2^-8 = 3.9e-3 relative in l at most; the normalised weights of the output sum to one exactly
