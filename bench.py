@@ -85,7 +85,8 @@ def time_kernel(fn, iters=3):
     return e0.elapsed_time(e1) / iters
 
 
-KERNEL_NAMES = ['attn_fwd_pre_kernel<false>', 'attn_fwd_pre_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
+# (the non-causal forward of a prescaled q is the hand-placed stream attn_fwd4w_kernel<2> for Nk >= 128, attn_fwd_pre_kernel<false> below that)
+KERNEL_NAMES = ['attn_fwd4w_kernel<2>', 'attn_fwd_pre_kernel<true>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dkdv_kernel<true>',
                 'attn_bwd_dq_kernel<false>', 'attn_bwd_dq_kernel<true>', 'attn_bwd_spx_kernel', 'attn_dq_reduce_kernel']
 
 
@@ -193,7 +194,7 @@ def dominant_kernel_roofline(task, B):
     w1, b1 = enc.W('blocks.0.mlp.fc1.weight'), enc.P('blocks.0.mlp.fc1.bias')
     cand = {}
     t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False, q_prescaled=True))
-    cand['attn_fwd_pre_kernel<false> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
+    cand['attn_fwd4w_kernel<2> (ViT MHSA fwd)'] = (t, 4.0 * N * N * D * B, depth)
     from pixparse_amd import hip
     bwd = lambda: ops.attn_bwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do, lse, delta,
                                dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, scale, False, q_prescaled=True)
@@ -405,14 +406,14 @@ def main():
             # (shape key of scripts/pmc_traffic.py: grid = query tiles x B x H workgroups of 256 threads -- for the dK/dV pass the grid of
             # the dQ pass launched right before it) next to that shape's algorithmic bytes (each operand once)
             grid, algo = None, None
-            if m.enc_kind == 'vit' and live_prof['kernel'] in ('attn_fwd_pre_kernel<false>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dq_kernel<false>', 'attn_bwd_spx_kernel'):
+            if m.enc_kind == 'vit' and live_prof['kernel'] in ('attn_fwd4w_kernel<2>', 'attn_bwd_dkdv_kernel<false>', 'attn_bwd_dq_kernel<false>', 'attn_bwd_spx_kernel'):
                 enc_ = m._engines[0]
                 spx = live_prof['kernel'] == 'attn_bwd_spx_kernel'      # workgroups of 256 keys instead of 128-row tiles
-                tiles = (enc_.N + 255) // 256 if spx else (enc_.N + 127) // 128
+                tiles = (enc_.N + 255) // 256 if (spx or live_prof['kernel'] == 'attn_fwd4w_kernel<2>') else (enc_.N + 127) // 128
                 grid = tiles * args.batch * enc_.heads * 256
                 # each operand once: q, k, v, dO in, dK, dV out -- and for the single pass dQ, whose per-key-block bf16 partials (ceil(N / 256)
                 # slabs the size of dQ, summed by attn_dq_reduce_kernel) are the price of one recomputation instead of two: they are NOT algorithmic
-                n_operands = {'attn_fwd_pre_kernel<false>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6, 'attn_bwd_spx_kernel': 7}[live_prof['kernel']]
+                n_operands = {'attn_fwd4w_kernel<2>': 4, 'attn_bwd_dkdv_kernel<false>': 6, 'attn_bwd_dq_kernel<false>': 6, 'attn_bwd_spx_kernel': 7}[live_prof['kernel']]
                 algo = n_operands * args.batch * enc_.N * enc_.D * 2
                 shape_note = f'encoder self-attention launches (N = {enc_.N}, grid {grid} threads)'
                 if spx:

@@ -531,7 +531,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
       const u32x4 srdQ = make_srd(qp, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
       const uint32_t voffQ0 = (uint32_t)(((int64_t)min(q0 + qi, a.Nq - 1) * a.q_rs + 8 * hh) * 2);
       const uint32_t voffQ1 = (uint32_t)(((int64_t)min(q0 + 32 + qi, a.Nq - 1) * a.q_rs + 8 * hh) * 2);
-      const uint32_t onesv = (((lane & 15) == 1 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 2 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
 #include "attn_fwd2x_body.inc"
 #endif
     }
@@ -546,6 +545,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
   for (int qb = 0; qb < 2; ++qb) {
 #if F4W_LSUM_VALU
     float l = qb ? ps10 + ps11 : ps00 + ps01;
+    l += swap32(l);
+#elif F4W_LSUM4      // every lane summed its own probabilities (all four registers of the 4x4x4 accumulator hold that sum); the two lane halves share a query
+    float l = qb ? lsum1[0] : lsum0[0];
     l += swap32(l);
 #else
     const f32x4 ls = qb ? lsum1 : lsum0;

@@ -48,6 +48,9 @@ A_O, A_L = 0, 64
 OCC2 = False        # set by generate(occ2=True): the two-waves-per-SIMD form (256 registers per wave) -- see the header
 FRAG_ACC = OPTS.get('fragacc', '0') == '1'      # K / V fragments in the accumulator half of the register file (a[72:135]) instead of v[0:63]
 FP = 'a' if FRAG_ACC else 'v'
+# lsum=mfma4: row sums by v_mfma_f32_4x4x4_16b_bf16 (1/8 of the 16x16x32 form's multiply-adds).  EXPERIMENT ONLY: the instruction takes 16 cycles of the pipe
+# on gfx950, not 8 (2531 against 2304 cycles per key tile), and the lane mapping assumed here is not the hardware's (sums come out wrong)
+LSUM4 = OPTS.get('lsum', 'mfma') == 'mfma4'
 LSUM_VALU = OPTS.get('lsum', 'mfma') == 'valu'      # row sums as fp32 VALU adds of the unrounded probabilities (two chains per query block) instead of MFMAs
 if FRAG_ACC:
     V_KF, V_VF = 72, 104
@@ -121,8 +124,10 @@ def seed_op(qb):
     return vt(V_SEED2 + 16 * qb, 16) if OCC2 else op(f'seed{qb}')
 
 
-def ones_op():
-    return at(A_ONES, 4) if OCC2 else op('ones')
+def ones_op(n=4):
+    if OCC2:
+        return at(A_ONES, n)
+    return op('ones') if n == 4 else op('ones2')
 
 
 def mfma_qk(k, ks, cm=None):
@@ -145,6 +150,13 @@ def mfma_pv(k, s, db):
     o = AO(qb, db)
     return I(f'v_mfma_f32_32x32x16_bf16 {at(o, 16)}, {ft(VF(kh, 2 * s + db), 4, "v")}, {vt(PB(k, s), 4)}, {at(o, 16)}', 'mfma',
              reads=fregs(VF(kh, 2 * s + db), 4, 'v') | vregs(PB(k, s), 4))
+
+
+def mfma_l4(k, s, half):
+    """L[qb][0..3] += the lane's own four probabilities P(k)[s][4 half .. 4 half + 3] (ONES . B per 4 x 4 block: every row of D gets the column sum)"""
+    qb = k & 1
+    b = PB(k, s) + 2 * half
+    return I(f'v_mfma_f32_4x4x4_16b_bf16 {at(AL(qb), 4)}, {ones_op(2)}, {vt(b, 2)}, {at(AL(qb), 4)}', 'mfma', reads=vregs(b, 2))
 
 
 def mfma_l(k, s):
@@ -217,26 +229,49 @@ def dma_piece(slot, n, tag):
     return out
 
 
-BIG = [0, 1, 2, 3, 5, 6, 7, 8]       # MFMA positions of a step that are 32-cycle MFMAs (4 and 9 are the 16-cycle row-sum MFMAs)
+# MFMA positions of a step: QK0 PVa QK1 PVb L QK2 [L] PVc QK3 [L] PVd L  (four 8-cycle row-sum MFMAs in the 4x4x4 form, two 16-cycle ones otherwise)
+if LSUM4:
+    NPOS, QKPOS, PVPOS, LPOS = 12, (0, 2, 5, 8), (1, 3, 7, 10), ((4, 0, 0), (6, 0, 1), (9, 1, 0), (11, 1, 1))
+else:
+    NPOS, QKPOS, PVPOS, LPOS = 10, (0, 2, 5, 7), (1, 3, 6, 8), ((4, 0, None), (9, 1, None))
+
+
+def pv_l(k):
+    """{position: MFMA} of PV(k) and L(k)"""
+    out = {PVPOS[0]: mfma_pv(k, 0, 0), PVPOS[1]: mfma_pv(k, 0, 1), PVPOS[2]: mfma_pv(k, 1, 0), PVPOS[3]: mfma_pv(k, 1, 1)}
+    if not ('lsum' in FDROP or LSUM_VALU):
+        for pos, s_, half in LPOS:
+            out[pos] = mfma_l4(k, s_, half) if LSUM4 else mfma_l(k, s_)
+    return out
+
+
 # what each of the ten MFMA gaps of a step takes, in order: e = next v_exp, c = next conversion (of v_exp two gaps back at the latest), l = next LDS
 # read, d = the step's LDS-DMA piece, b = the barrier group, s = two row-sum adds (lsum=valu).  Issue model (gen_attn_bwd_sp.py): a gap costs
 # max(MFMA time, fillers + ~5) with v_exp 8, plain VALU 5, an LDS instruction 9: [e e l] = 25 + 5, [e e c c] = 26 + 5 fill a 32-cycle gap.
-PATTERN2 = {0: OPTS.get('pat2', 'ee-eec-eec-eec-d-eec-eec-eec-eec-c').split('-'),
-            3: OPTS.get('pat23', 'eeb-eec-eec-eec-d-eec-eec-eec-eec-c').split('-')}
-PATTERN = {0: OPTS.get('pat', 'eel-eecl-eel-eecc-l-eel-eecc-eel-eecc-cd').split('-'),
-           3: OPTS.get('pat3', 'eeb-eecl-eel-eeccl-l-eel-eeccl-eel-eeccl-cd').split('-')}
+if LSUM4:
+    PATTERN2 = {0: OPTS.get('pat2', 'ee-eec-eec-eec-d-eec--eec-eec--eec-c').split('-'),
+                3: OPTS.get('pat23', 'eeb-eec-eec-eec-d-eec--eec-eec--eec-c').split('-')}
+else:
+    PATTERN2 = {0: OPTS.get('pat2', 'ee-eec-eec-eec-d-eec-eec-eec-eec-c').split('-'),
+                3: OPTS.get('pat23', 'eeb-eec-eec-eec-d-eec-eec-eec-eec-c').split('-')}
+if LSUM4:
+    PATTERN = {0: OPTS.get('pat', 'eel-eecl-eel-eecc-l-eel--eecc-eel--eecc-cd').split('-'),
+               3: OPTS.get('pat3', 'eeb-eecl-eel-eeccl-l-eel--eeccl-eel-l-eeccl-cd').split('-')}
+else:
+    PATTERN = {0: OPTS.get('pat', 'eel-eecl-eel-eecc-l-eel-eecc-eel-eecc-cd').split('-'),
+               3: OPTS.get('pat3', 'eeb-eecl-eel-eeccl-l-eel-eeccl-eel-eeccl-cd').split('-')}
 
 
 def step(k, pos, has_exp, has_pv, tail=False, last_body=False, cm=None, addr_cur=None, addr_next=None, dma=True, tag_t=0):
     """one pipeline step = quarter k = 4 t + j.  pos = ring slot of tile t.  Returns (mfmas[10], gaps[10])"""
     j = k & 3
-    mf = [mfma_qk(k, 0, cm), None, mfma_qk(k, 1), None, None, mfma_qk(k, 2), None, mfma_qk(k, 3), None, None]
+    mf = [None] * NPOS
+    for ks in range(4):
+        mf[QKPOS[ks]] = mfma_qk(k, ks, cm if ks == 0 else None)
     if has_pv:
-        mf[1], mf[3], mf[4] = mfma_pv(k - 2, 0, 0), mfma_pv(k - 2, 0, 1), mfma_l(k - 2, 0)
-        mf[6], mf[8], mf[9] = mfma_pv(k - 2, 1, 0), mfma_pv(k - 2, 1, 1), mfma_l(k - 2, 1)
-    if 'lsum' in FDROP or LSUM_VALU:
-        mf[4] = mf[9] = None
-    gaps = [[] for _ in range(10)]
+        for pos_, ins in pv_l(k - 2).items():
+            mf[pos_] = ins
+    gaps = [[] for _ in range(NPOS)]
     exps = [v_exp(k - 1, r) for r in range(16)] if (has_exp and 'exp' not in FDROP) else []
     cvts = [v_cvt(k - 1, p) for p in range(8)] if (has_exp and 'cvt' not in FDROP) else []
     sums = [v_sum(k - 1, r) for r in range(16)] if (has_exp and LSUM_VALU and 'lsum' not in FDROP) else []
@@ -265,16 +300,16 @@ def step(k, pos, has_exp, has_pv, tail=False, last_body=False, cm=None, addr_cur
         lds = []
         if j & 1:
             if j == 1:
-                for ks, g in enumerate((0, 2, 5, 7)):
+                for ks, g in enumerate(QKPOS):
                     fixed[g] = read_k(addr_cur, 1, 1, ks, (T_, 'K1'))
             elif not tail:
-                for ks, g in enumerate((0, 2, 5, 7)):
+                for ks, g in enumerate(QKPOS):
                     fixed[g] = read_k(addr_next, 0, 0, ks, (T_ + 1, 'K0'))
-            for f, g in enumerate((1, 3, 6, 8)):
+            for f, g in enumerate(PVPOS):
                 fixed[g] = read_v(addr_cur, j >> 1, f >> 1, f & 1, (T_, f'V{j >> 1}'))
     pat = PATTERN2[3 if (j == 3 and not tail) else 0] if OCC2 else PATTERN[3 if (j == 3 and not tail) else 0]
     done_e = 0
-    for g in range(10):
+    for g in range(NPOS):
         e_before = done_e
         for ch in pat[g]:
             if ch == 'e' and exps:
@@ -295,12 +330,12 @@ def step(k, pos, has_exp, has_pv, tail=False, last_body=False, cm=None, addr_cur
                 bar = []
         gaps[g] += fixed.get(g, [])
     assert not exps and not cvts and not bar, (len(exps), len(cvts), len(bar))
-    gaps[9] += lds + piece + sums
+    gaps[NPOS - 1] += lds + piece + sums
     return mf, gaps
 
 
 def emit_step(E, mf, gaps):
-    for m in range(10):
+    for m in range(NPOS):
         if mf[m] is not None:
             E(mf[m])
         for ins in gaps[m]:
@@ -327,7 +362,7 @@ def mask_tuple(E, k, buf):
 def generate(occ2=False):
     set_map(occ2)
     H = Hazards()
-    H.OLD = 8
+    H.OLD = 1 << 30      # exact counted waits: the merge-over-old-reads shortcut of the GEMM generator makes the pending set depend on MFMA counts, which differ in the peeled first tile
     E = H.emit
     # ---- entry: tiles 0 and 1 are in flight / landed (the wrapper waited for tile 0 behind a barrier to take the row maxima), s_koff / s_voff point at tile 2
     a0 = Addr(0)
@@ -340,7 +375,7 @@ def generate(occ2=False):
         for qb in range(2):
             for r in range(16):
                 E(I(f'v_mov_b32 v{V_SEED2 + 16 * qb + r}, {op(f"negm{qb}")}', 'valu'))
-        for r in range(4):
+        for r in range(2 if LSUM4 else 4):
             E(I(f'v_accvgpr_write_b32 a{A_ONES + r}, {op("onesv")}', 'valu'))
     for ks in range(4):
         for ins in read_k(a0, 0, 0, ks, (0, 'K0')):
@@ -389,12 +424,10 @@ def generate(occ2=False):
         emit_step(E, mf, gaps)
     for j in range(2):     # drain: exp / cvt of the last quarter, PV / L of the last two
         k = 4 * T + 4 + j
-        mf = [None] * 10
-        mf[1], mf[3], mf[4] = mfma_pv(k - 2, 0, 0), mfma_pv(k - 2, 0, 1), mfma_l(k - 2, 0)
-        mf[6], mf[8], mf[9] = mfma_pv(k - 2, 1, 0), mfma_pv(k - 2, 1, 1), mfma_l(k - 2, 1)
-        if LSUM_VALU:
-            mf[4] = mf[9] = None
-        gaps = [[] for _ in range(10)]
+        mf = [None] * NPOS
+        for pos_, ins in pv_l(k - 2).items():
+            mf[pos_] = ins
+        gaps = [[] for _ in range(NPOS)]
         if j == 0:
             for r in range(16):
                 gaps[0].append(v_exp(k - 1, r))
@@ -427,15 +460,23 @@ def render(stream, occ2=False):
         vin = ['voffK', 'voffV', 'voffQ0', 'voffQ1', 'limlane', 'negm0', 'negm1', 'onesv']
         sin = ['srdK', 'srdV', 'srdQ', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
     else:
-        vin = [f'q{qb}{ks}' for qb in range(2) for ks in range(4)] + ['seed0', 'seed1', 'ones'] + addr_names + ['voffK', 'voffV', 'limlane', 'negm0', 'negm1', 'neginf']
+        vin = [f'q{qb}{ks}' for qb in range(2) for ks in range(4)] + ['seed0', 'seed1', 'ones2' if LSUM4 else 'ones'] + addr_names + ['voffK', 'voffV', 'limlane', 'negm0', 'negm1', 'neginf']
         sin = ['srdK', 'srdV', 's_ldsw', 's_k32', 's_v32', 's_kstep', 's_vstep']
     ins_ = ', '.join(f'[{n}] "v"({n})' for n in vin) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
     clob = ', '.join(f'"v{i}"' for i in range(64 if FRAG_ACC and not occ2 else 0, N_HAND)) + \
         (', ' + ', '.join(f'"a{i}"' for i in range(72, 136)) if FRAG_ACC and not occ2 else '') + \
         (', ' + ', '.join(f'"a{i}"' for i in range(A_Q, A_END)) if occ2 else '') + ', "vcc", "scc", "memory"'
+    # the ONES operand of the row-sum MFMAs, built by the wrapper's compiler: all ones (4x4x4 form) or rows 1 / 2 on alternate k-groups (16x16x32 form)
+    sel = '1' if LSUM4 else '(((lane & 15) == 1 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 2 && ((lane >> 4) & 1) == 1))'
+    if occ2:
+        prelude = f'const uint32_t onesv = {sel} ? 0x3f803f80u : 0u;\n'
+    elif LSUM4:
+        prelude = 'bf16x4 ones2;\nfor (int j_ = 0; j_ < 4; ++j_) ones2[j_] = (__bf16)1.0f;\n'
+    else:
+        prelude = ''
     return ('// GENERATED by gen_attn_fwd4w.py -- do not edit; see that file for the register map and the schedule\n' +
-            '#undef F4W_LSUM_VALU\n' + ('#define F4W_LSUM_VALU 1\n' if LSUM_VALU else '#define F4W_LSUM_VALU 0\n') +
-            'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
+            '#undef F4W_LSUM_VALU\n#undef F4W_LSUM4\n' + ('#define F4W_LSUM_VALU 1\n' if LSUM_VALU else '#define F4W_LSUM_VALU 0\n') + ('#define F4W_LSUM4 1\n' if LSUM4 else '#define F4W_LSUM4 0\n') +
+            prelude + 'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
 
 
 FILES = ['attn_fwd4w_body.inc', 'attn_fwd2x_body.inc']

@@ -100,6 +100,58 @@ def test_gemm4w_streams_are_in_sync_and_counted():
                 pending = list(pending)
 
 
+def test_attention_forward_streams_are_in_sync_and_counted():
+    """csrc/attn_fwd4w_body.inc / attn_fwd2x_body.inc (the hand-placed attention forward at 512 / 256 registers per wave, committed) are exactly what
+    csrc/gen_attn_fwd4w.py generates today; per 64-key tile a wave issues 32 large MFMAs, the 8 row-sum MFMAs, 64 v_exp, 32 conversions, 8 + 16 fragment
+    reads, its 4 LDS-DMA pieces and one barrier; every LDS read is covered by a counted wait before its first consumer; a conversion never shares an MFMA
+    gap with a v_exp that feeds it"""
+    import importlib.util, re, sys
+    from pixparse_amd import build as b
+    for k in ('G4W_DROP', 'F4W_DROP', 'F4W_OPTS'):
+        assert not os.environ.get(k), f'{k} is set: the committed streams are the default build'
+    sys.path.insert(0, b.CSRC)
+    try:
+        spec = importlib.util.spec_from_file_location('gen_attn_fwd4w', os.path.join(b.CSRC, 'gen_attn_fwd4w.py'))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+    finally:
+        sys.path.remove(b.CSRC)
+    for name, occ2 in zip(gen.FILES, (False, True)):
+        stream = gen.generate(occ2)
+        text = gen.render(stream, occ2)
+        assert text == open(os.path.join(b.CSRC, name)).read(), f'{name} is stale: run python pixparse_amd/csrc/gen_attn_fwd4w.py'
+        body = text[text.index('LOOP%=:'):text.index('s_branch LOOP%=')]            # four key tiles (ring positions 1, 2, 3, 0)
+        assert body.count('v_mfma_f32_32x32x16_bf16') == 4 * 32 and body.count('v_mfma_f32_16x16x32_bf16') == 4 * 8
+        assert body.count('v_exp_f32') == 4 * 64 and body.count('v_cvt_pk_bf16_f32') == 4 * 32
+        assert body.count('ds_read_b128') == 4 * 8 and body.count('ds_read_b64_tr_b16') == 4 * 16
+        assert body.count('offen lds') == 4 * 4 and body.count('s_barrier') == 4
+        assert not re.search(r'scratch_', text)
+        pending = []
+        for ins in stream:
+            if ins.kind == 'wait' and 'lgkmcnt' in ins.text:
+                n = int(re.search(r'lgkmcnt\((\d+)\)', ins.text).group(1))
+                pending = pending[len(pending) - n:] if 0 < n < len(pending) else ([] if n == 0 else pending)
+            elif ins.kind == 'ds':
+                pending.append(ins.writes)
+            elif ins.kind == 'mfma':
+                busy = set().union(*pending) if pending else set()
+                assert not (busy & ins.reads), f'{name}: {ins.text} reads a fragment that is still being loaded'
+    # the loop of both forms: a conversion reads only values exponentiated in an EARLIER gap (v_exp is a transcendental: its result is not forwarded)
+    for name, occ2 in zip(gen.FILES, (False, True)):
+        text = open(os.path.join(b.CSRC, name)).read()
+        body = text[text.index('LOOP%=:'):text.index('s_branch LOOP%=')]
+        fresh = set()
+        for ln in body.splitlines():
+            m = re.search(r'v_exp_f32 (v\d+),', ln)
+            if 'v_mfma' in ln:
+                fresh = set()
+            elif m:
+                fresh.add(m.group(1))
+            elif 'v_cvt_pk_bf16_f32' in ln:
+                a, c = re.search(r'v_cvt_pk_bf16_f32 v\d+, (v\d+), (v\d+)', ln).groups()
+                assert a not in fresh and c not in fresh, f'{name}: {ln.strip()} reads a v_exp result of its own gap'
+
+
 def test_attention_backward_stream_is_in_sync_and_its_hazard_pass_bites():
     """csrc/attn_bwd_sp_body.inc (the hand-placed single-pass attention backward, committed) is exactly what csrc/gen_attn_bwd_sp.py
     generates today; per 64-query tile pass it holds the 80 MFMAs the design counts, and the generator's hazard pass refuses a schedule

@@ -701,7 +701,8 @@ def test_gemm_round_model_calibration(dev):
     model of the wave-quantisation cut for THIS device.  Plausible numbers, and results of a cut GEMM unchanged."""
     from pixparse_amd import hip, ops
     a, b, cal = ops.gemm_calibrate(dev, force=True)
-    assert cal and 0.0 <= a < 30.0 and 11.0 < b < 44.0, (a, b, cal)            # one round of 256 tiles: ~20-50 us at K = 1024 on an MI355X
+    assert cal and 0.0 <= a < 40.0 and 8.0 < b < 60.0, (a, b, cal)             # one round of 256 tiles: ~20-50 us at K = 1024 on an MI355X (a timing: wide bounds, the
+    # clock of a short launch depends on what ran before it -- 14-16 / 31-33 alone, outside 30 / 44 once in the middle of the suite)
     M, N, K = 256 * 64 + 232, 1024, 2048
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.05, 2, BF16)
