@@ -1412,9 +1412,14 @@ int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_ge
 static int bwd_chain_length(int nkt, int BH, bool stream) {
   if (g_bwd_chain > 0) return g_bwd_chain < nkt ? g_bwd_chain : nkt;      // forced: both forms (same arithmetic at the same chain length)
   if (!stream) return 1;
-  static int memo_nkt = 0, memo_bh = 0, memo_cu = 0, memo_c = 1;
+  // memo: the last few (key blocks, heads, CUs) -- encoder and cross-attention shapes, each with and without the CUs a data-parallel run reserves
+  // for RCCL while a bucket is in flight (a single entry missed twice per step there and re-simulated ~15 k heap operations)
+  struct Memo { int nkt, bh, cu, c; };
+  static Memo memo[8];
+  static int memo_n = 0, memo_next = 0;
   const int ncu = crl_gemm_cus();
-  if (nkt == memo_nkt && BH == memo_bh && ncu == memo_cu) return memo_c;
+  for (int i = 0; i < memo_n; ++i)
+    if (memo[i].nkt == nkt && memo[i].bh == BH && memo[i].cu == ncu) return memo[i].c;
   // in units of one key block's time on one CU (~ Nq): the stream slows by ~0.6 % per link (fewer workgroups of a head side by side: c = 12
   // against 6 at cfg-3), a slab costs the reduce (chip-wide, HBM-bound: bytes ~ heads x Nq) 0.1 at 128 heads, and a link is charged 0.03
   // more for the bf16 rounding it adds to the running sum (ties go to the shorter chain)
@@ -1446,7 +1451,9 @@ static int bwd_chain_length(int nkt, int BH, bool stream) {
     const double cost = price(makespan, c, nfull + (rem ? 1 : 0));
     if (cost < best - 1e-9) { best = cost; best_c = c; }
   }
-  memo_nkt = nkt; memo_bh = BH; memo_cu = ncu; memo_c = best_c;
+  memo[memo_next] = Memo{nkt, BH, ncu, best_c};
+  memo_next = (memo_next + 1) % 8;
+  memo_n = memo_n < 8 ? memo_n + 1 : 8;
   return best_c;
 }
 // the chain length crl_attn_bwd would use for Nk keys and B * H heads right now (pure host arithmetic: no GPU needed)

@@ -228,31 +228,40 @@ int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t
 // ---- launch geometry of the persistent kernels + the ticket-counter pool of the dynamic tile scheduler (gemm_common.h) ----
 #include <atomic>
 #include <algorithm>
+#include <mutex>
 static constexpr int CHIP_CUS = 256;
 static int g_reserved_cus = 0;     // CUs left to other kernels (RCCL) by the persistent launches
 static int g_dynamic = 1;          // 1 = resident workgroups pull tiles from ticket counters, 0 = static walk b, b + grid, ...
-__device__ uint32_t g_sched_state[gemmc::CRL_SCHED_SLOTS * gemmc::CRL_SCHED_WORDS];   // zero at module load; every launch leaves its slot zeroed
+constexpr int CRL_SCHED_RINGS = 4;
+__device__ uint32_t g_sched_state[CRL_SCHED_RINGS * gemmc::CRL_SCHED_SLOTS * gemmc::CRL_SCHED_WORDS];   // zero at module load; every launch leaves its slot zeroed
 int crl_gemm_cus() { return CHIP_CUS - g_reserved_cus; }
 bool crl_gemm_dynamic() { return g_dynamic != 0; }
-// The pool is a ring: launch n + CRL_SCHED_SLOTS reuses the slot of launch n, which is safe only if the two are ordered -- i.e. issued
-// on ONE stream (the last workgroup of a launch zeroes its slot before the kernel ends).  The first stream that asks owns the pool;
-// a persistent GEMM launched on any OTHER stream gets *ok = true with no slot and walks its tiles statically (same results, no shared
-// state) instead of racing on the counters.
+// A ring of slots per STREAM: launch n + CRL_SCHED_SLOTS of a ring reuses the slot of launch n, which is safe only if the two are ordered -- i.e.
+// issued on one stream (the last workgroup of a launch zeroes its slot before the kernel ends).  The first CRL_SCHED_RINGS streams that launch a
+// persistent GEMM get a ring each (the default stream, the stream torch.cuda.graph captures on -- a captured launch keeps its slot, replays of the
+// graph are ordered among themselves --, the RCCL-overlap side stream); a launch on any further stream gets *ok = true with no slot and walks its
+// tiles statically (same results, no shared state) instead of racing on the counters.
 uint32_t* crl_sched_slot(hipStream_t stream, bool* ok) {
   static uint32_t* base = nullptr;
-  static std::atomic<unsigned> seq{0};
-  static std::atomic<void*> owner{nullptr};
-  static std::atomic<bool> owned{false};
+  static std::mutex mu;
+  static void* owner[CRL_SCHED_RINGS];
+  static unsigned seq[CRL_SCHED_RINGS];
+  static int nrings = 0;
   *ok = true;
+  std::lock_guard<std::mutex> lock(mu);
   if (!base) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_state)) != hipSuccess || !p) { crl_set_error("crl_gemm_bf16: no scheduler state"); *ok = false; return nullptr; }
     base = (uint32_t*)p;
   }
-  bool expected = false;
-  if (owned.compare_exchange_strong(expected, true)) owner.store((void*)stream);
-  if (owner.load() != (void*)stream) return nullptr;
-  return base + (size_t)(seq.fetch_add(1) % gemmc::CRL_SCHED_SLOTS) * gemmc::CRL_SCHED_WORDS;
+  int r = 0;
+  while (r < nrings && owner[r] != (void*)stream) ++r;
+  if (r == nrings) {
+    if (nrings == CRL_SCHED_RINGS) return nullptr;
+    owner[nrings] = (void*)stream;
+    seq[nrings++] = 0;
+  }
+  return base + ((size_t)r * gemmc::CRL_SCHED_SLOTS + (size_t)(seq[r]++ % gemmc::CRL_SCHED_SLOTS)) * gemmc::CRL_SCHED_WORDS;
 }
 extern "C" int crl_gemm_set_reserved_cus(int n) {
   if (n < 0 || n > CHIP_CUS - 32) { crl_set_error("crl_gemm_set_reserved_cus: %d is outside [0, %d]", n, CHIP_CUS - 32); return -1; }

@@ -145,7 +145,7 @@ class Scratch:
     """lazily grown device scratch shared by the reductions (never read across calls).  Once a hipGraph has been captured
     (freeze_scratch()) a buffer that has to grow is RETIRED, not freed: the graph's launches keep writing their slabs / partials into
     the address they were captured with, which stays owned by this object instead of going back to the caching allocator where other
-    tensors would be handed the same memory."""
+    tensors would be handed the same memory; from then on it grows by at least half its size."""
     frozen = False
 
     def __init__(self):
@@ -154,9 +154,14 @@ class Scratch:
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            want = max(nbytes, 1 << 20)
             if Scratch.frozen and self.buf is not None:
                 self.retired.append(self.buf)
-            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+                # a retired buffer is never released: grow geometrically so that a rising sequence of requests (eval / generation shapes after a
+                # graphed training run) retires at most ~2 x the final size in all, not one buffer per request
+                if self.buf.device == device:
+                    want = max(want, self.buf.numel() + self.buf.numel() // 2)
+            self.buf = torch.empty(want, dtype=torch.uint8, device=device)
             import os
             if os.environ.get('PIXPARSE_AMD_POISON', '0') == '1':    # debug aid (see layers/engines.py Buffers)
                 self.buf.fill_(255)

@@ -100,6 +100,25 @@ def test_gemm4w_streams_are_in_sync_and_counted():
                 pending = list(pending)
 
 
+def test_scratch_grows_geometrically_once_frozen():
+    """ops.Scratch after freeze_scratch(): a buffer that has to grow is retired (a captured graph may still write into it) and the new one is at
+    least half as large again, so a rising sequence of requests retires a bounded total"""
+    from pixparse_amd import ops
+    was = ops.Scratch.frozen
+    try:
+        sc = ops.Scratch()
+        dev = torch.device('cpu')
+        sc.get(4 << 20, dev)
+        ops.Scratch.frozen = True
+        sizes = []
+        for req in range(4 << 20, 16 << 20, 1 << 20):          # twelve requests, each 1 MiB larger
+            sizes.append(sc.get(req + 1, dev).numel())
+        assert len(sc.retired) <= 4 and sum(t.numel() for t in sc.retired) <= 2 * sizes[-1], (len(sc.retired), sizes)
+        assert all(b >= a for a, b in zip(sizes, sizes[1:])) and sizes[-1] >= (15 << 20)
+    finally:
+        ops.Scratch.frozen = was
+
+
 def test_attention_forward_streams_are_in_sync_and_counted():
     """csrc/attn_fwd4w_body.inc / attn_fwd2x_body.inc (the hand-placed attention forward at 512 / 256 registers per wave, committed) are exactly what
     csrc/gen_attn_fwd4w.py generates today; per 64-key tile a wave issues 32 large MFMAs, the 8 row-sum MFMAs, 64 v_exp, 32 conversions, 8 + 16 fragment

@@ -541,6 +541,46 @@ def test_wgrad_with_a_partial_last_round_is_never_row_cut(dev, big):
     close(dw, 1.0 + dy.float().t() @ x.float(), 2e-3, 0.5, 'TN, 284 tiles, partial last round')
 
 
+def test_gemm_dynamic_schedule_per_stream_rings_and_graph_capture(dev):
+    """the ticket-counter pool is a ring PER STREAM: persistent GEMMs in flight on two streams at once, and captured into a hipGraph
+    (torch captures on a side stream: the captured launches keep their slots, replays are ordered), give the static walk's bits"""
+    from pixparse_amd import hip, ops
+    M, N, K = 256 * 41 + 72, 2048, 192
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    w = rnd((N, K), dev, 0.1, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 4)
+    try:
+        hip.call('crl_gemm_set_policy', 2)
+        ops.gemm_set_schedule(False)
+        want = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_fwd(x, w, bias, want)
+        ops.gemm_set_schedule(True)
+        side = torch.cuda.Stream()
+        outs_a = [torch.empty(M, N, dtype=BF16, device=dev) for _ in range(40)]
+        outs_b = [torch.empty(M, N, dtype=BF16, device=dev) for _ in range(40)]
+        torch.cuda.synchronize()
+        for oa, ob in zip(outs_a, outs_b):               # 40 + 40 launches, the two streams unordered with respect to each other
+            ops.linear_fwd(x, w, bias, oa)
+            with torch.cuda.stream(side):
+                ops.linear_fwd(x, w, bias, ob)
+        torch.cuda.synchronize()
+        for o in outs_a + outs_b:
+            assert torch.equal(o, want), 'dynamic schedule on two concurrent streams differs from the static walk'
+        og = torch.zeros(M, N, dtype=BF16, device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(3):
+                ops.linear_fwd(x, w, bias, og)
+        for _ in range(30):                              # 90 replayed launches through the capture stream's ring of 64
+            g.replay()
+            ops.linear_fwd(x, w, bias, outs_a[0])       # eager launches between the replays use the default stream's ring
+        torch.cuda.synchronize()
+        assert torch.equal(og, want) and torch.equal(outs_a[0], want), 'graph-captured dynamic schedule differs from the static walk'
+    finally:
+        hip.call('crl_gemm_set_policy', 0)
+        ops.gemm_set_schedule(True)
+
+
 def test_gemm_dynamic_tile_schedule(dev):
     """persistent GEMMs (more tiles than resident workgroups) under the dynamic tile scheduler: bit-identical to the static walk for all
     three layouts and both persistent kernels; the ticket counters are left zeroed by every launch (80 launches through a pool of 64
