@@ -510,7 +510,19 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
   f32x16 o00 = zero16(), o01 = zero16(), o10 = zero16(), o11 = zero16();
   f32x4 lsum0 = f32x4{0.f, 0.f, 0.f, 0.f}, lsum1 = f32x4{0.f, 0.f, 0.f, 0.f};      // row sums on the matrix pipe ...
   float ps00 = 0.f, ps01 = 0.f, ps10 = 0.f, ps11 = 0.f;                              // ... or as VALU adds (generator option lsum=valu)
-  {
+  // a wave whose 64 queries all lie past Nq (N = 6189: three of the four waves of a head's last block) only keeps the workgroup's staging going: its
+  // four LDS-DMA pieces per tile and the tile's barrier, exactly as the stream issues them -- no matrix work, no energy
+  const bool wave_live = __builtin_amdgcn_readfirstlane(q0 < a.Nq ? 1 : 0) != 0;
+  if (!wave_live) {
+    for (int t = 0; t + 1 < nt; ++t) {
+      const uint32_t slot = sbase + (uint32_t)((t + 2) & 3) * 16384u;
+      stage64(srdK, slot, sk, (t + 2) * 64, a.k_rs, wave);
+      stage64(srdV, slot + 8192, sv, (t + 2) * 64, a.v_rs, wave);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile t + 1 has landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
     const int limlane = (a.Nk - (nt - 1) * 64) - 4 * hh;      // last tile: key row 32 kh + (r & 3) + 8 (r >> 2) of this lane half is valid iff < limlane
     const uint32_t voffK = sk.v, voffV = sv.v;
     const uint32_t s_ldsw = sbase + (uint32_t)wave * 1024u;
@@ -577,6 +589,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
       if (hh == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qabs] = (m[qb] + __builtin_amdgcn_logf(l)) * LN2;
     }
   }
+  if (!wave_live) chk = 0.f;
   // any non-finite l or output (NaN * 0 = NaN) -> the workgroup runs its two 128-query halves again with the moving maximum
 #ifdef F4W_NO_FALLBACK      // timing-only variants of the stream (scripts/ab_f4w.sh) produce garbage on purpose
   chk = 0.f;
@@ -1358,7 +1371,8 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   // algorithmic FLOPs: QK^T and PV, 2 x 2 x Nq x Nk x 64 per head (a causal mask halves them when Nq == Nk)
   const double pairs = causal ? (double)Nq * (Nk - Nq) + 0.5 * (double)Nq * (Nq + 1) : (double)Nq * Nk;
   CRL_PROF_START(CRL_K_ATTN_FWD + (causal ? 1 : 0), stream, 4.0 * 64 * pairs * B * H);
-  if (q_prescaled && !drop && !causal && g_fwd_mode != 1 && Nk >= 128) {
+  // (the 256-register form loads its Q fragments through a buffer descriptor: 32-bit offsets)
+  if (q_prescaled && !drop && !causal && g_fwd_mode != 1 && Nk >= 128 && (uint64_t)(Nq + 64) * (uint64_t)q_rs * 2 < (1ull << 32)) {
     // the hand-placed stream: 256 queries per workgroup, two workgroups per CU (mode 3: the 512-register form, one per CU; mode 2: every block also
     // runs its moving-maximum fallback -- tests)
     static bool configured = false;

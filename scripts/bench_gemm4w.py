@@ -65,6 +65,13 @@ if __name__ == '__main__':
         case(f'{tag} dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, rounds=1)
         case(f'{tag} dgrad proj', 'NN', M, 1024, 1024, rounds=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'epi2x':    # the epilogue-heavy launches: automatic plan (8-wave 256x256) against the 256x128 two-per-CU kernel (policy 3)
+        for pol in (0, 3, 0, 3):
+            case(f'fc1 gelu pol {pol}', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU, policy=pol, rounds=1)
+            case(f'dgrad fc2 dgelu pol {pol}', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, policy=pol, rounds=1)
+            case(f'proj resid pol {pol}', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, policy=pol, rounds=1)
+            case(f'fc2 resid pol {pol}', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, policy=pol, rounds=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'wide':     # very wide outputs: automatic plan (256x128 two-per-CU kernel) against the forced 256x256 kernels
         for pol in (0, 2, 3):
             case(f'lm head pol {pol}', 'NT', 8184, 50304, 1024, policy=pol, rounds=1)
