@@ -1,7 +1,8 @@
 #!/bin/bash
 # round-5 end-of-round artifacts (one gpurun call): the default bench line, the rocprofv3 kernel trace of the same command (stats + per launch
-# shape), the GEMM PMC groups (4-wave against 8-wave kernel at 8192^3), the yardstick against the vendor libraries, the other configs.
+# shape), the two HBM-traffic PMC passes, the GEMM and forward-attention PMC groups (4-wave against 8-wave kernel at 8192^3), the yardstick against the vendor libraries, the other configs.
 # Everything lands in gpurun_out/; the summaries are copied to profiles/ by hand.
+ulimit -c 0
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
@@ -9,8 +10,17 @@ python bench.py > gpurun_out/r5_bench_default_output.json 2> gpurun_out/r5_bench
 cut -c1-300 gpurun_out/r5_bench_default_output.json
 bash scripts/gpu_trace.sh r5_final > gpurun_out/r5_final_trace.txt 2>&1
 bash scripts/gpu_trace_shapes.sh r5_final > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-host-leg --no-peak > $R/gpurun_out/pmc_$c.log 2>&1
+done
+cd $R
+python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/r5_pmc_traffic.json | head -30
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 bash scripts/gpu_pmc_gemm.sh r5 > /dev/null 2>&1
 cat gpurun_out/r5_pmc_gemm.txt
+bash scripts/gpu_pmc_attn_fwd.sh r5 > /dev/null 2>&1
+cat gpurun_out/r5_pmc_attn_fwd.txt
 bash scripts/gpu_yardstick.sh > /dev/null 2>&1
 for spec in "cruller_small 2" "cruller_base_960x640 8" "cruller_large_6layers 2"; do
   set -- $spec
