@@ -449,6 +449,9 @@ __device__ unsigned long long* g_f4w_stamps = nullptr;
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, int force_fallback) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
+#if F4W_STAMPS
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31, hh = lane >> 5;
@@ -548,7 +551,12 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
     }
 #if F4W_STAMPS
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-    if (g_f4w_stamps && tid == 0) g_f4w_stamps[blockIdx.x] = st1 - st0;
+    if (g_f4w_stamps && tid == 0) {      // [0] stream cycles, [1] / [2] entry of the kernel / end of the stream in 10-ns ticks (s_memrealtime), [3] HW_ID | XCC_ID << 32
+      g_f4w_stamps[4 * blockIdx.x] = st1 - st0;
+      g_f4w_stamps[4 * blockIdx.x + 1] = rt0;
+      g_f4w_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+      g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
 #endif
   }
   // ---- epilogue: l of query (lane & 31) sits in lanes 0..15, register 1 (queries 0..15) / 2 (queries 16..31) of the row-sum accumulators

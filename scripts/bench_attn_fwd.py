@@ -7,6 +7,33 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def timeline(rec, what):
+    """per-CU occupancy of the last launch from the diagnostic build's records: [stream cycles, t_entry, t_end (10-ns ticks), HW_ID | XCC_ID << 32]"""
+    import collections
+    t0 = int(rec[:, 1].min())
+    t_end = int(rec[:, 2].max()) - t0
+    cus = collections.defaultdict(list)
+    for i in range(rec.shape[0]):
+        hw = int(rec[i, 3])
+        key = ((hw >> 32) & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)       # (xcc, se, sh, cu)
+        cus[key].append((int(rec[i, 1]) - t0, int(rec[i, 2]) - t0, i))
+    busy2 = busy1 = 0
+    last_start = []
+    for key, ivs in cus.items():
+        ev = sorted([(a, 1) for a, b, _ in ivs] + [(b, -1) for a, b, _ in ivs])
+        n, prev = 0, 0
+        for t, d in ev:
+            if n >= 2: busy2 += t - prev
+            elif n == 1: busy1 += t - prev
+            n += d; prev = t
+        last_start.append(max(a for a, b, _ in ivs))
+    ncu = len(cus)
+    per = sorted(len(v) for v in cus.values())
+    print(f'  timeline ({what}): {ncu} CUs seen, kernel span {t_end / 100:.1f} us; CU time with two workgroups resident {100 * busy2 / (ncu * t_end):.1f} %, with one {100 * busy1 / (ncu * t_end):.1f} %, '
+          f'idle {100 * (1 - (busy1 + busy2) / (ncu * t_end)):.1f} %; workgroups per CU min {per[0]} median {per[len(per) // 2]} max {per[-1]}; last workgroup start at {max(last_start) / 100:.1f} us, '
+          f'median CU\'s last start {sorted(last_start)[len(last_start) // 2] / 100:.1f} us', flush=True)
+
+
 NAMES = {0: 'stream, 1 wave / SIMD  ', 1: '32 q per wave          ', 4: 'stream, 2 waves / SIMD '}
 
 
@@ -18,7 +45,7 @@ def main():
     stamps = None
     if hasattr(lib, 'crl_debug_f4w_stamps'):      # diagnostic builds: cycles of the stream statement per workgroup
         import ctypes
-        stamps = torch.zeros(8 * 16 * 25, dtype=torch.int64, device=dev)
+        stamps = torch.zeros(4 * 8 * 16 * 25, dtype=torch.int64, device=dev)
         lib.crl_debug_f4w_stamps.argtypes = [ctypes.c_void_p]
         lib.crl_debug_f4w_stamps(stamps.data_ptr())
     shapes = [('vit', 8, 16, 6189, 6189), ('cross', 8, 16, 1023, 6189)]
@@ -57,7 +84,11 @@ def main():
                 elif ref is not None:
                     extra = f'  rel diff vs mode 1: {float((o.float() - ref.float()).norm() / ref.float().norm()):.2e}'
                 if stamps is not None and mode != 1 and name == 'vit':
-                    st = stamps[:B * H * ((Nq + 255) // 256)].float()
+                    nwg = B * H * ((Nq + 255) // 256)
+                    rec = stamps[:4 * nwg].view(nwg, 4).cpu()
+                    st = rec[:, 0].float()
+                    if 'timeline' in sys.argv:
+                        timeline(rec, NAMES[mode])
                     extra += f'  stream cycles per workgroup: mean {float(st.mean()):.0f} min {float(st.min()):.0f} max {float(st.max()):.0f} = {float(st.mean()) / ((Nk + 63) // 64):.0f} per key tile'
                 print(f'{name:6s} B{B} H{H} Nq{Nq} Nk{Nk} round {rnd} {NAMES[mode]}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s{extra}', flush=True)
         hip.call('crl_attn_fwd_set_mode', 0)
