@@ -1,38 +1,49 @@
 #!/usr/bin/env python3
-"""Generates attn_fwd4w_body.inc: the hand-placed gfx950 instruction stream of the one-wave-per-SIMD attention forward (attention.hip:
-attn_fwd4w_kernel; non-causal, head_dim 64, q prescaled by scale * log2 e).
+"""Generates attn_fwd2x_body.inc / attn_fwd4w_body.inc: the hand-placed gfx950 instruction stream of the attention forward (attention.hip:
+attn_fwd4w_kernel<OCC>; non-causal, no dropout, head_dim 64, q prescaled by scale * log2 e) at 256 / 512 registers per wave.
 
-Workgroup = 256 queries of one (batch, head) = 4 waves, ONE WAVE PER SIMD with the whole 512-entry register file; a wave owns 64 queries = two
-32-query blocks qb, so every K row fragment and every V^T fragment it reads from LDS feeds TWO v_mfma_f32_32x32x16_bf16 (the 32-queries-per-wave
-kernel reads 1 KiB of LDS per MFMA = the whole LDS bandwidth of the CU at the MFMA rate; this one half of it).  Per 64-key tile a wave issues
+Workgroup = 256 queries of one (batch, head) = 4 waves; a wave owns 64 queries = two 32-query blocks qb, so every K row fragment and every V^T
+fragment it reads from LDS feeds TWO v_mfma_f32_32x32x16_bf16 (the 32-queries-per-wave kernel reads 1 KiB of LDS per MFMA = the whole LDS bandwidth
+of the CU at the MFMA rate; this one half of it).  Per 64-key tile a wave issues
   16 MFMAs  S^T = K . Q^T + seed   (query on the lane, the 32 keys of a half kh in the 16 accumulator registers; seed = -m in every register)
   64 v_exp_f32 (in place) + 32 v_cvt_pk_bf16_f32 -> the P^T fragments (accumulator order = the k order of the transposed V reads: no lane exchange)
   16 MFMAs  O^T += V^T . P^T      (O in a[0:63])
-   8 v_mfma_f32_16x16x32_bf16  L += ONES . P^T: the row sums on the matrix pipe (a 16-cycle MFMA instead of 8 VALU adds of 4 cycles: the
+   8 v_mfma_f32_16x16x32_bf16  L += ONES . P^T: the row sums on the matrix pipe (a 16-cycle MFMA instead of 8 VALU adds of 4 cycles: a lone wave's
      stream is bound by VALU ISSUE, not by the pipe).  A lane of the 16x16x32 B operand holds query (lane & 15) + 16 (k-group & 1), so the ONES
      operand has row 1 = 1 on k-groups 0 / 2, row 2 = 1 on k-groups 1 / 3: L[1][n] = row sum of query n, L[2][n] = of query n + 16 (a[64:71]).
 The reference m is the exact row maximum over the FIRST key tile (the wrapper computes it) and never moves: probabilities are 2^(s - m), up to
 2^127 -- bf16 and fp32 have the exponent range, the relative precision of p, l and O does not depend on it.  A row whose later scores exceed
 its first tile's maximum by more than 127 (or whose sums overflow) ends with a non-finite l or O: the wrapper detects that at the end of the
-block and the WORKGROUP re-runs the block with the moving-maximum kernel body (attn_fwd_pre: never seen outside the forced test).
+block and the WORKGROUP re-runs the block with the moving-maximum kernel body (fwd_pre_block: never seen outside the forced test).
 
 Software pipeline over quarters k = 4 t + j (tile t, key half kh = j >> 1, query block qb = j & 1), one step per quarter:
-  step k:  MFMAs  QK(k) [4]  |  PV(k - 2) [4] + L(k - 2) [2 small]      VALU: exp / cvt of quarter k - 1 (two v_exp + one cvt per 32-cycle gap)
-MFMA order QK0 PVa QK1 PVb La QK2 PVc QK3 PVd Lb: no MFMA follows one that writes its accumulator.  Fragment registers are double sets indexed by
-kh; LDS reads of a set are issued while the other set is in use:
-  step 4t    : K[kh1](t) ks 0,1 ; V[kh0](t) s 0          step 4t + 2: V[kh1](t) s 0
-  step 4t + 1: K[kh1](t) ks 2,3 ; V[kh0](t) s 1          step 4t + 3: BARRIER(t + 1) ; K[kh0](t + 1) ; V[kh1](t) s 1
+  step k:  MFMAs  QK(k) [4]  |  PV(k - 2) [4] + L(k - 2) [2 small]      VALU: exp / cvt of quarter k - 1 (two v_exp + one cvt per 32-cycle gap; a
+           conversion never sits in the gap of a v_exp that feeds it: the transcendental's result is not forwarded)
+MFMA order QK0 PVa QK1 PVb La QK2 PVc QK3 PVd Lb: no MFMA follows one that writes its accumulator.
 K / V tiles (8 KiB + 8 KiB, the swizzled 64 x 64 image of attn_frag.h) arrive by LDS-DMA two tiles ahead into a ring of four 16-KiB slots (64 KiB:
 every ds_read offset is an immediate); each wave issues 4 of the 16 pieces of a tile, one per step; one barrier per tile (tile t + 1 landed for
 every wave, slot of tile t - 2 free).  Tiles past the end arrive as zeros (bounds-checked descriptor).  The loop is unrolled four-fold (ring
 period); the first tile is peeled (nothing to exponentiate / accumulate yet); the LAST tile runs in a tail with register-based slot addressing whose
 S chains start from seed-or-minus-infinity tuples (keys >= Nk masked: built in the tail, 32 VALU per quarter), followed by the drain of the pipeline.
 
-Registers (hand-allocated v[0 : N_HAND); the wrapper's operands -- Q fragments, seeds, ONES, lane addresses -- live above):
-  v[0:31]   K row fragments [kh][ks] x 4        v[32:63]  V^T fragments [kh][2 s + db] x 4
-  v[64:95]  S / P accumulators, two sets        v[96:111] P^T bf16 fragments, two sets x [s] x 4
-  v[112:143] masked seed tuples (tail)          v[144:151] slot-relative lane addresses (tail)
-  a[0:63]   O^T [qb][db] x 16                   a[64:71]  L [qb] x 4
+TWO FORMS of this pipeline (generate(occ2)); measured: profiles/r5_attn_fwd_stream.txt:
+ * 512 registers, one workgroup per CU (attn_fwd4w_body.inc).  Fragment registers are double sets indexed by kh; the LDS reads of a set are issued
+   while the other set is in use (step 4t: K[kh1](t) ks 0,1 + V[kh0](t) s 0 | 4t + 1: ks 2,3 + s 1 | 4t + 2: V[kh1](t) s 0 | 4t + 3: BARRIER(t + 1),
+   K[kh0](t + 1), V[kh1](t) s 1), placed by the PATTERN tables.  v[0:31] K fragments [kh][ks] x 4, v[32:63] V^T fragments [kh][2 s + db] x 4, v[64:95]
+   S / P accumulators (two sets), v[96:111] P^T fragments (two sets x [s] x 4), v[112:143] masked seed tuples (tail), v[144:151] slot-relative lane
+   addresses (tail); Q fragments, seeds, ONES are the wrapper's register-tuple operands.  A LONE WAVE ISSUES IN ORDER: its exp / cvt fill the gaps
+   and every further instruction costs its ~5 issue cycles: 1500 cycles per tile against 1152 of matrix-pipe time, wherever the fillers sit.
+ * 256 registers, TWO workgroups per CU (attn_fwd2x_body.inc; the default): the second wave on each SIMD issues into the first one's stalls and
+   the pair runs at the pipe's rate (2304 cycles per tile for the two).  Single fragment sets, each register re-read right behind its last use (odd
+   steps, ten MFMAs ahead of the next use); LLVM splits a 256-register budget 128 + 128, so v[0:15] K fragments, v[16:47] S / P sets, v[48:63] P^T
+   fragments, v[64:95] seed tuples (C and D of an MFMA share a register file and the VALU exponentiates S), a[72:103] Q fragments (loaded by the
+   stream itself from memory), a[104:107] ONES, a[108:123] V^T fragments; the tail masks straight into the S set and advances the lane addresses in
+   place.  No register-tuple operands at all (hipcc's allocator does not terminate on the tuple form at this budget).
+Both: a[0:63] O^T [qb][db] x 16, a[64:71] L [qb] x 4.  Same arithmetic, bit-identical results.
+
+Options (timing experiments: scripts/ab_f4w.sh): F4W_OPTS=pat=..,pat3=..,pat2=..,pat23=.. filler placement tables; lsum=valu row sums as fp32 VALU adds
+of the unrounded probabilities (+4 % time); lsum=mfma4 the 4x4x4 MFMA form (experiment only, see below); fragacc=1 (512-register form: fragments in
+the accumulator half, nothing).  F4W_DROP=exp,cvt,lsum,lgkwait and G4W_DROP=dsread,dma,barrier,vmwait: timing-only builds with WRONG results.
 """
 import os
 import sys
