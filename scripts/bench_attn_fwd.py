@@ -86,6 +86,7 @@ def main():
                 if stamps is not None and mode != 1 and name == 'vit':
                     nwg = B * H * ((Nq + 255) // 256)
                     rec = stamps[:4 * nwg].view(nwg, 4).cpu()
+                    rec = rec[rec[:, 1] > 0]              # workgroups that ran the stream (a short last block runs the 32-queries-per-wave body: no record)
                     st = rec[:, 0].float()
                     if 'timeline' in sys.argv:
                         timeline(rec, NAMES[mode])
