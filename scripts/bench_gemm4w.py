@@ -72,6 +72,14 @@ if __name__ == '__main__':
             case(f'proj resid pol {pol}', 'NT', M, 1024, 1024, ops.EPI_F32_RESID, policy=pol, rounds=1)
             case(f'fc2 resid pol {pol}', 'NT', M, 1024, 4096, ops.EPI_F32_RESID, policy=pol, rounds=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'decoder':    # the decoder's M = 8184 GEMMs with 1024 output columns (128 tiles of 256 x 256: the automatic plan takes the 128 x 128 kernel)
+        Md = 8184
+        for pol in (0, 2, 3, 0, 2, 3):
+            case(f'dec proj pol {pol}', 'NT', Md, 1024, 1024, ops.EPI_F32_RESID, policy=pol, rounds=1)
+            case(f'dec fc2 pol {pol}', 'NT', Md, 1024, 4096, ops.EPI_F32_RESID, policy=pol, rounds=1)
+            case(f'dec dgrad K1024 pol {pol}', 'NN', Md, 1024, 1024, policy=pol, rounds=1)
+            case(f'dec dgrad K4096 pol {pol}', 'NN', Md, 4096, 1024, policy=pol, rounds=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'wide':     # very wide outputs: automatic plan (256x128 two-per-CU kernel) against the forced 256x256 kernels
         for pol in (0, 2, 3):
             case(f'lm head pol {pol}', 'NT', 8184, 50304, 1024, policy=pol, rounds=1)
