@@ -535,6 +535,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
     uint32_t akr0 = sbase + la.row[0], akr1 = sbase + la.row[1], akr2 = sbase + la.row[2], akr3 = sbase + la.row[3];
     uint32_t avt00 = sbase + la.tr[0][0], avt01 = sbase + la.tr[0][1], avt10 = sbase + la.tr[1][0], avt11 = sbase + la.tr[1][1];
 #if F4W_STAMPS
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (OCC == 1) {
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
       g_f4w_stamps[4 * blockIdx.x] = st1 - st0;
       g_f4w_stamps[4 * blockIdx.x + 1] = rt0;
       g_f4w_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-      g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                         ((rt1 - rt0) << 40);      // bits 40..: ticks from kernel entry to the stream's first instruction (prologue)
     }
 #endif
   }

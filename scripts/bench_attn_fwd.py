@@ -15,7 +15,7 @@ def timeline(rec, what):
     cus = collections.defaultdict(list)
     for i in range(rec.shape[0]):
         hw = int(rec[i, 3])
-        key = ((hw >> 32) & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)       # (xcc, se, sh, cu)
+        key = ((hw >> 32) & 0xff, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)       # (xcc, se, sh, cu)
         cus[key].append((int(rec[i, 1]) - t0, int(rec[i, 2]) - t0, i))
     busy2 = busy1 = 0
     last_start = []
@@ -27,6 +27,10 @@ def timeline(rec, what):
             elif n == 1: busy1 += t - prev
             n += d; prev = t
         last_start.append(max(a for a, b, _ in ivs))
+    pro = ((rec[:, 3] >> 40) & 0xffffff).float()
+    dur = (rec[:, 2] - rec[:, 1]).float()
+    print(f'  per workgroup: entry -> end of stream {float(dur.mean()) / 100:.1f} us (min {float(dur.min()) / 100:.1f}, max {float(dur.max()) / 100:.1f}), of which prologue {float(pro.mean()) / 100:.2f} us '
+          f'(max {float(pro.max()) / 100:.2f}); stream {float(rec[:, 0].float().mean()):.0f} s_memtime ticks = {float(rec[:, 0].float().mean()) / (float((dur - pro).mean()) * 10):.3f} ticks per ns')
     ncu = len(cus)
     per = sorted(len(v) for v in cus.values())
     print(f'  timeline ({what}): {ncu} CUs seen, kernel span {t_end / 100:.1f} us; CU time with two workgroups resident {100 * busy2 / (ncu * t_end):.1f} %, with one {100 * busy1 / (ncu * t_end):.1f} %, '
