@@ -1175,6 +1175,9 @@ __device__ unsigned long long spx_trace[6 * (SPX_TR_WG + 1) * SPX_TR_PASSES];
 // the tile's first dQ MFMA), so a chain leaves ONE slab and attn_dq_reduce_kernel adds ceil(nkt / chain) of them instead of nkt.
 __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if F4W_STAMPS      // diagnostic builds: entry / exit of every workgroup in 10-ns ticks + where it ran (scripts/bench_attn_fwd.py bwd timeline)
+  const unsigned long long dbg_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // longest first: the nfull = nkt / chain full chains of every (batch, head), then the remainders (workgroups start in index order, so
   // the short ones fill the last round)
@@ -1277,6 +1280,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
     if (threadIdx.x == 0 && blockIdx.x < 4096) { spx_dbg[2 * blockIdx.x] = c1 - c0; spx_dbg[2 * blockIdx.x + 1] = r1 - r0; }
 #endif
   }
+#if F4W_STAMPS
+  if (g_f4w_stamps && threadIdx.x == 0) {
+    g_f4w_stamps[4 * blockIdx.x] = (unsigned long long)(kb_end - cidx * chain);      // key blocks of this chain
+    g_f4w_stamps[4 * blockIdx.x + 1] = dbg_rt0;
+    g_f4w_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 }
 
 // dq[b, q, h*64 + d] = bf16(scale * sum over slabs (fp32, in slab order) of slab[s][b][q][h*64 + d]); 16 bytes per thread and slab

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def timeline(rec, what):
+def timeline(rec, what, per_wg=True):
     """per-CU occupancy of the last launch from the diagnostic build's records: [stream cycles, t_entry, t_end (10-ns ticks), HW_ID | XCC_ID << 32]"""
     import collections
     t0 = int(rec[:, 1].min())
@@ -29,8 +29,15 @@ def timeline(rec, what):
         last_start.append(max(a for a, b, _ in ivs))
     pro = ((rec[:, 3] >> 40) & 0xffffff).float()
     dur = (rec[:, 2] - rec[:, 1]).float()
-    print(f'  per workgroup: entry -> end of stream {float(dur.mean()) / 100:.1f} us (min {float(dur.min()) / 100:.1f}, max {float(dur.max()) / 100:.1f}), of which prologue {float(pro.mean()) / 100:.2f} us '
+    if per_wg:
+      print(f'  per workgroup: entry -> end of stream {float(dur.mean()) / 100:.1f} us (min {float(dur.min()) / 100:.1f}, max {float(dur.max()) / 100:.1f}), of which prologue {float(pro.mean()) / 100:.2f} us '
           f'(max {float(pro.max()) / 100:.2f}); stream {float(rec[:, 0].float().mean()):.0f} s_memtime ticks = {float(rec[:, 0].float().mean()) / (float((dur - pro).mean()) * 10):.3f} ticks per ns')
+    xcc = collections.defaultdict(list)
+    for key, ivs in cus.items():
+        xcc[key[0]] += ivs
+    print('  per XCD: ' + '  '.join(f'x{k}: {len(v)} wg, last end {max(b for a, b, _ in v) / 100:.0f} us, mean dur {sum(b - a for a, b, _ in v) / len(v) / 100:.0f}' for k, v in sorted(xcc.items())), flush=True)
+    ends = sorted(max(b for a, b, _ in ivs) for ivs in cus.values())
+    print(f'  CU finish times: min {ends[0] / 100:.0f} us, 10 % {ends[len(ends) // 10] / 100:.0f}, median {ends[len(ends) // 2] / 100:.0f}, 90 % {ends[9 * len(ends) // 10] / 100:.0f}, max {ends[-1] / 100:.0f}', flush=True)
     ncu = len(cus)
     per = sorted(len(v) for v in cus.values())
     print(f'  timeline ({what}): {ncu} CUs seen, kernel span {t_end / 100:.1f} us; CU time with two workgroups resident {100 * busy2 / (ncu * t_end):.1f} %, with one {100 * busy1 / (ncu * t_end):.1f} %, '
@@ -54,6 +61,30 @@ def main():
         lib.crl_debug_f4w_stamps(stamps.data_ptr())
     shapes = [('vit', 8, 16, 6189, 6189), ('cross', 8, 16, 1023, 6189)]
     one = 'one' in sys.argv
+    if 'bwd' in sys.argv and stamps is not None:      # where the workgroups of the single-pass backward ran and when (diagnostic build)
+        B, H, N = 8, 16, 6189
+        D = H * 64
+        g = torch.Generator(device=dev).manual_seed(1)
+        qkv = torch.randn(B, N, 3 * D, generator=g, device=dev).to(torch.bfloat16)
+        qp = (qkv[:, :, :D].float() * 0.125 * ops.LOG2E).to(torch.bfloat16)
+        k, v = qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+        o = torch.empty(B, N, D, dtype=torch.bfloat16, device=dev); lse = torch.empty(B, H, N, device=dev)
+        do = torch.randn(B, N, D, generator=g, device=dev).to(torch.bfloat16)
+        dqkv = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device=dev); delta = torch.empty(2, B, H, N, device=dev)
+        ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+        for rep in range(3):
+            stamps.zero_()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.attn_bwd(qp, k, v, o, do, lse, delta, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], H, 0.125, False, q_prescaled=True)
+            e1.record()
+            torch.cuda.synchronize()
+            rec = stamps.view(-1, 4).cpu()
+            rec = rec[rec[:, 1] > 0]
+            print(f'backward (delta + single pass + reduce) {e0.elapsed_time(e1):.3f} ms, {rec.shape[0]} workgroups of the single pass; chain lengths {sorted(set(rec[:, 0].tolist()))}')
+            timeline(rec, 'single-pass backward', per_wg=False)
+        return
     if one:
         shapes = shapes[:1]
     for name, B, H, Nq, Nk in shapes:
