@@ -198,6 +198,11 @@ int crl_attn_bwd_set_mode(int mode);
  * depend on it; dQ carries one more bf16 rounding of the running sum per link (3.5e-3 instead of 2.6e-3 relative L2 against fp32 at
  * chain 4, 25 key blocks).  crl_attn_bwd_ws_bytes stays sized for chain 1. */
 int crl_attn_bwd_set_chain(int chain);
+/* Single pass only: the key blocks a head has left over after its full chains (nkt % chain) are walked by TWO workgroups that take half of the query
+ * tiles each when that shortens the launch (cfg-3: 3200 key blocks over 256 CUs = 12.5 per CU -- without the split half the CUs walk 13): dQ rows are
+ * disjoint, the second half's dK / dV go to a scratch behind the slabs and are added to the first half's by a small kernel (one more bf16 rounding on
+ * those key rows).  -1 (default) = decided with the automatic chain from the simulated makespan; 0 = never; 1 = whenever legal (tests). */
+int crl_attn_bwd_set_qsplit(int mode);
 /* the chain length the hand-placed single pass would use for Nk keys and BH = B * H heads under the current settings (forced chain,
  * reserved CUs); host arithmetic only */
 int crl_attn_bwd_chain_for(int Nk, int BH);

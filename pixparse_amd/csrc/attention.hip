@@ -1173,7 +1173,12 @@ __device__ unsigned long long spx_trace[6 * (SPX_TR_WG + 1) * SPX_TR_PASSES];
 // One workgroup = a CHAIN of `chain` consecutive 256-key blocks of one (batch, head), walked one after the other: the partial dQ of a key
 // block is added to what the blocks before it in the chain left in the slab (read back tile by tile through LDS-DMA, as the C operand of
 // the tile's first dQ MFMA), so a chain leaves ONE slab and attn_dq_reduce_kernel adds ceil(nkt / chain) of them instead of nkt.
-__global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull) {
+// QUERY SPLIT of the remainder chains (qsplit): when the nkt % chain key blocks every head has left over would occupy only part of the chip for a
+// whole block time (cfg-3: 3200 key blocks over 256 CUs = 12.5 -- half the CUs walk 13), each remainder chain is run by TWO workgroups that take half
+// of the query tiles each: dQ rows are disjoint (same slab), the second half writes its dK / dV to a compact scratch [B H][rows][64] behind the slabs
+// and attn_bwd_addkv_kernel adds it to the first half's (one more bf16 rounding on those key rows).
+__global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull, int qsplit,
+                                                                u16* __restrict__ tmpkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if F4W_STAMPS      // diagnostic builds: entry / exit of every workgroup in 10-ns ticks + where it ran (scripts/bench_attn_fwd.py bwd timeline)
   const unsigned long long dbg_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1181,41 +1186,54 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // longest first: the nfull = nkt / chain full chains of every (batch, head), then the remainders (workgroups start in index order, so
   // the short ones fill the last round)
-  int bh, cidx;
+  int bh, cidx, qhalf = -1;
   const int nfull_wg = nfull * a.B * a.H;
   if ((int)blockIdx.x < nfull_wg) block_to_bh_tile(blockIdx.x, nfull, a.B * a.H, bh, cidx);
-  else { block_to_bh_tile(blockIdx.x - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
+  else if (!qsplit) { block_to_bh_tile(blockIdx.x - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
+  else { block_to_bh_tile(blockIdx.x - nfull_wg, 2, a.B * a.H, bh, qhalf); cidx = nfull; }
   const int b = bh / a.H, h = bh % a.H;
   const int HD2 = a.H * 64 * 2;                    // bytes per slab row
+  // the query rows this workgroup walks: all of them, or one half of the 64-query tiles (query split of a remainder chain)
+  int q_row0 = 0, nq = a.Nq;
+  if (qhalf >= 0) {
+    const int h0 = (((a.Nq + 63) / 64 + 1) / 2) * 64;
+    if (qhalf == 0) nq = h0; else { q_row0 = h0; nq = a.Nq - h0; }
+  }
 
-  const u32x4 rq = make_srd(a.q + b * a.q_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.q_rs + 64) * 2));
-  const u32x4 rdo = make_srd(a.d_o + b * a.do_bs + h * 64, (uint32_t)(((int64_t)(a.Nq - 1) * a.do_rs + 64) * 2));
+  const u32x4 rq = make_srd(a.q + b * a.q_bs + (int64_t)q_row0 * a.q_rs + h * 64, (uint32_t)(((int64_t)(nq - 1) * a.q_rs + 64) * 2));
+  const u32x4 rdo = make_srd(a.d_o + b * a.do_bs + (int64_t)q_row0 * a.do_rs + h * 64, (uint32_t)(((int64_t)(nq - 1) * a.do_rs + 64) * 2));
   const u32x4 rk = make_srd(a.k + b * a.k_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.k_rs + 64) * 2));
   const u32x4 rv = make_srd(a.v + b * a.v_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.v_rs + 64) * 2));
-  const u32x4 rdk = make_srd(a.dk + b * a.dk_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dk_rs + 64) * 2));
-  const u32x4 rdv = make_srd(a.dv + b * a.dv_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dv_rs + 64) * 2));
-  const u16* slab = slabs + (int64_t)cidx * slab_stride + (int64_t)b * a.Nq * (a.H * 64);
-  const u32x4 rslab = make_srd(slab, (uint32_t)((int64_t)a.Nq * HD2));
+  // dK / dV: the outputs, or -- second half of a query split -- compact rows [key - key_base][64] of this (batch, head) in the scratch
+  const bool to_tmp = qhalf == 1;
+  const int key_base = nfull * chain * 256, tmp_rows = a.Nk - key_base;
+  const int64_t dk_rs = to_tmp ? 64 : a.dk_rs, dv_rs = to_tmp ? 64 : a.dv_rs;
+  const u16* tdk = tmpkv + (int64_t)bh * tmp_rows * 64 - (int64_t)key_base * 64;
+  const u32x4 rdk = to_tmp ? make_srd(tdk, (uint32_t)((int64_t)a.Nk * 128)) : make_srd(a.dk + b * a.dk_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dk_rs + 64) * 2));
+  const u32x4 rdv = to_tmp ? make_srd(tdk + (int64_t)a.B * a.H * tmp_rows * 64, (uint32_t)((int64_t)a.Nk * 128))
+                           : make_srd(a.dv + b * a.dv_bs + h * 64, (uint32_t)(((int64_t)(a.Nk - 1) * a.dv_rs + 64) * 2));
+  const u16* slab = slabs + (int64_t)cidx * slab_stride + ((int64_t)b * a.Nq + q_row0) * (a.H * 64);
+  const u32x4 rslab = make_srd(slab, (uint32_t)((int64_t)nq * HD2));
   const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
   // row constants: wave 1 fetches -delta, the others -lse/scale (waves 2 / 3 into spare vectors of the slot: every wave issues the same five pieces)
-  const float* rcp = wave == 1 ? a.delta + ((int64_t)b * a.H + h) * a.Nq : a.delta + nrows + ((int64_t)b * a.H + h) * a.Nq;
-  const u32x4 rrc = make_srd(rcp, (uint32_t)a.Nq * 4u);
+  const float* rcp = (wave == 1 ? a.delta + ((int64_t)b * a.H + h) * a.Nq : a.delta + nrows + ((int64_t)b * a.H + h) * a.Nq) + q_row0;
+  const u32x4 rrc = make_srd(rcp, (uint32_t)nq * 4u);
   const uint32_t sbase = lds_addr_of(smem);
   const int qh = wave >> 1, dbq = wave & 1;        // dQ phase: this wave's block = d rows 32 dbq.., q columns 32 qh..
-  const int nqt64 = (a.Nq + 63) / 64;
+  const int nqt64 = (nq + 63) / 64;
   const uint32_t s_qstep = (uint32_t)(64 * a.q_rs * 2), s_dostep = (uint32_t)(64 * a.do_rs * 2);
   const uint32_t s_q32 = (uint32_t)(32 * a.q_rs * 2), s_do32 = (uint32_t)(32 * a.do_rs * 2);
-  const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_slab3 = 3u * s_slabstep, s_dk32 = (uint32_t)(32 * a.dk_rs * 2), s_dv32 = (uint32_t)(32 * a.dv_rs * 2);
+  const uint32_t s_slabstep = (uint32_t)(64 * HD2), s_slab3 = 3u * s_slabstep, s_dk32 = (uint32_t)(32 * dk_rs * 2), s_dv32 = (uint32_t)(32 * dv_rs * 2);
   const float s_dkscale = a.scale;
   const uint32_t s_iters = (uint32_t)nqt64;        // + the drain behind the loop: dV / dK of the last block, dQ of the last tile
   const uint32_t s_m0q = sbase + wave * 1024, s_m0rc = sbase + 16384 + wave * 256;     // + ring slot + piece: immediates of the unrolled passes
   const uint32_t s_m0p = sbase + SPX_PART + wave * 2048;                                // + partial buffer + piece
-  const uint32_t s_krs2 = (uint32_t)(a.k_rs * 2), s_vrs2 = (uint32_t)(a.v_rs * 2), s_dkrs2 = (uint32_t)(a.dk_rs * 2), s_dvrs2 = (uint32_t)(a.dv_rs * 2);
+  const uint32_t s_krs2 = (uint32_t)(a.k_rs * 2), s_vrs2 = (uint32_t)(a.v_rs * 2), s_dkrs2 = (uint32_t)(dk_rs * 2), s_dvrs2 = (uint32_t)(dv_rs * 2);
 
   const int kb_end = min(a.nkt, (cidx + 1) * chain);
   for (int kblk = cidx * chain; kblk < kb_end; ++kblk) {
     // the first key block of a chain starts from zero: a descriptor without records returns zeros
-    const u32x4 rprev = make_srd(slab, kblk == cidx * chain ? 0u : (uint32_t)((int64_t)a.Nq * HD2));
+    const u32x4 rprev = make_srd(slab, kblk == cidx * chain ? 0u : (uint32_t)((int64_t)nq * HD2));
     // every per-lane value is derived afresh from an OPAQUE copy of the thread index: hoisted out of the key-block loop it would have to
     // live across the stream, which leaves the compiler 32 vector registers (26 of them its operands) -- i.e. in scratch memory
     int tid = threadIdx.x;
@@ -1288,6 +1306,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
     g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
   }
 #endif
+}
+
+// query split of the remainder chains: dk / dv rows key_base .. Nk - 1 (+)= the second half's compact partials; 16 bytes per thread and array
+__global__ __launch_bounds__(256) void attn_bwd_addkv_kernel(const AttnArgs a, const u16* __restrict__ tmpkv, int key_base) {
+  const int tmp_rows = a.Nk - key_base;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;                 // over B H x tmp_rows x 8 chunks
+  if (i >= (int64_t)a.B * a.H * tmp_rows * 8) return;
+  const int c8 = (int)(i & 7);
+  const int r = (int)((i >> 3) % tmp_rows);
+  const int bh = (int)((i >> 3) / tmp_rows);
+  const int b = bh / a.H, h = bh % a.H;
+  const u16* t = tmpkv + ((int64_t)bh * tmp_rows + r) * 64 + c8 * 8;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    u16* dst = (which ? a.dv + b * a.dv_bs + (int64_t)(key_base + r) * a.dv_rs : a.dk + b * a.dk_bs + (int64_t)(key_base + r) * a.dk_rs) + h * 64 + c8 * 8;
+    const uint4 x = *reinterpret_cast<const uint4*>(dst), y = *reinterpret_cast<const uint4*>(t + (which ? (int64_t)a.B * a.H * tmp_rows * 64 : 0));
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf2f(xs[j] & 0xffff) + bf2f(ys[j] & 0xffff), bf2f(xs[j] >> 16) + bf2f(ys[j] >> 16));
+    *reinterpret_cast<uint4*>(dst) = uint4{o[0], o[1], o[2], o[3]};
+  }
 }
 
 // dq[b, q, h*64 + d] = bf16(scale * sum over slabs (fp32, in slab order) of slab[s][b][q][h*64 + d]); 16 bytes per thread and slab
@@ -1444,17 +1484,27 @@ int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_ge
 // The workgroups start longest first -- nfull = nkt / c full chains per head, then the remainders --; the makespan of that order on the
 // available CUs is simulated once per (nkt, heads, CUs) and the cheapest c kept.  Same-box A/B at cfg-3 (25 key blocks, 128 heads):
 // c = 3 / 4 / 6 within noise of each other, -2.5 ms per step against c = 1, c = 12 half of that (profiles/r4_attn_chain.txt).
-static int bwd_chain_length(int nkt, int BH, bool stream) {
+static int g_bwd_qsplit = -1;      // query split of the remainder chains: -1 auto (with the automatic chain only), 0 off, 1 whenever legal
+extern "C" int crl_attn_bwd_set_qsplit(int mode) {
+  if (mode < -1 || mode > 1) { crl_set_error("crl_attn_bwd_set_qsplit: -1 auto, 0 off, 1 whenever legal"); return -1; }
+  g_bwd_qsplit = mode;
+  return 0;
+}
+static int bwd_chain_length(int nkt, int BH, bool stream, int* qsplit = nullptr) {
+  if (qsplit) *qsplit = g_bwd_qsplit == 1;
   if (g_bwd_chain > 0) return g_bwd_chain < nkt ? g_bwd_chain : nkt;      // forced: both forms (same arithmetic at the same chain length)
   if (!stream) return 1;
   // memo: the last few (key blocks, heads, CUs) -- encoder and cross-attention shapes, each with and without the CUs a data-parallel run reserves
   // for RCCL while a bucket is in flight (a single entry missed twice per step there and re-simulated ~15 k heap operations)
-  struct Memo { int nkt, bh, cu, c; };
+  struct Memo { int nkt, bh, cu, c, split; };
   static Memo memo[8];
   static int memo_n = 0, memo_next = 0;
   const int ncu = crl_gemm_cus();
   for (int i = 0; i < memo_n; ++i)
-    if (memo[i].nkt == nkt && memo[i].bh == BH && memo[i].cu == ncu) return memo[i].c;
+    if (memo[i].nkt == nkt && memo[i].bh == BH && memo[i].cu == ncu) {
+      if (qsplit && g_bwd_qsplit == -1) *qsplit = memo[i].split;
+      return memo[i].c;
+    }
   // in units of one key block's time on one CU (~ Nq): the stream slows by ~0.6 % per link (fewer workgroups of a head side by side: c = 12
   // against 6 at cfg-3), a slab costs the reduce (chip-wide, HBM-bound: bytes ~ heads x Nq) 0.1 at 128 heads, and a link is charged 0.03
   // more for the bf16 rounding it adds to the running sum (ties go to the shorter chain)
@@ -1486,7 +1536,34 @@ static int bwd_chain_length(int nkt, int BH, bool stream) {
     const double cost = price(makespan, c, nfull + (rem ? 1 : 0));
     if (cost < best - 1e-9) { best = cost; best_c = c; }
   }
-  memo[memo_next] = Memo{nkt, BH, ncu, best_c};
+  // query split of the remainder chains (two workgroups of half the query tiles each instead of one): worth it when it shortens the simulated
+  // makespan by at least half a key block (the second half's dK / dV cost one more small kernel and a bf16 rounding)
+  int best_split = 0;
+  {
+    const int c = best_c, nfull = nkt / c, rem = nkt % c;
+    if (rem > 0 && (int64_t)(nfull + 2) * BH <= 64 * (int64_t)ncu) {
+      int span[2];
+      for (int sp = 0; sp < 2; ++sp) {          // lengths in half key blocks
+        std::fill(busy.begin(), busy.end(), 0);
+        auto later = [](int x, int y) { return x > y; };
+        int makespan = 0;
+        auto place = [&](int n, int len) {
+          for (int i = 0; i < n && len > 0; ++i) {
+            std::pop_heap(busy.begin(), busy.end(), later);
+            busy.back() += len;
+            makespan = busy.back() > makespan ? busy.back() : makespan;
+            std::push_heap(busy.begin(), busy.end(), later);
+          }
+        };
+        place(nfull * BH, 2 * c);
+        place(sp ? 2 * BH : BH, sp ? rem : 2 * rem);
+        span[sp] = makespan;
+      }
+      best_split = span[1] + 1 <= span[0];
+    }
+  }
+  if (qsplit && g_bwd_qsplit == -1) *qsplit = best_split;
+  memo[memo_next] = Memo{nkt, BH, ncu, best_c, best_split};
   memo_next = (memo_next + 1) % 8;
   memo_n = memo_n < 8 ? memo_n + 1 : 8;
   return best_c;
@@ -1575,17 +1652,31 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");
     a.nkt = (Nk + 255) / 256;
-    const int chain = bwd_chain_length(a.nkt, B * H, q_prescaled && g_bwd_mode != 3);
+    const bool spx = q_prescaled && g_bwd_mode != 3;
+    int want_split = 0;
+    const int chain = bwd_chain_length(a.nkt, B * H, spx, &want_split);
     const int nfull = a.nkt / chain, nchain = (a.nkt + chain - 1) / chain;
     const int nslab = nchain;
     const int64_t slab_stride = (int64_t)B * Nq * H * 64;
+    // query split of the remainder chains: the hand-placed stream only, at least two query tiles per half, scratch behind the slabs in use
+    const int key_base = nfull * chain * 256;
+    const int64_t tmp_elems = 2 * (int64_t)B * H * (Nk - key_base) * 64;
+    const bool qsplit = spx && want_split && nchain > nfull && (Nq + 63) / 64 >= 4 &&
+                        (uint64_t)(nchain * slab_stride + tmp_elems) * 2 <= (uint64_t)ws_bytes && (uint64_t)Nk * 128 < (1ull << 32);
+    u16* const tmpkv = (u16*)ws + (int64_t)nchain * slab_stride;
+    const unsigned grid_spx = (unsigned)(nfull + (nchain > nfull ? (qsplit ? 2 : 1) : 0)) * B * H;
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
-    if (q_prescaled && g_bwd_mode != 3) attn_bwd_spx_kernel<<<(unsigned)nchain * B * H, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
+    if (spx) attn_bwd_spx_kernel<<<grid_spx, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull, qsplit ? 1 : 0, tmpkv);
     else if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
     else attn_bwd_sp_kernel<false><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
     CRL_PROF_STOP(CRL_K_ATTN_BWD_FUSED, stream);
     CRL_LAUNCH_CHECK("crl_attn_bwd(fused)");
+    if (qsplit) {
+      const int64_t nadd = (int64_t)B * H * (Nk - key_base) * 8;
+      attn_bwd_addkv_kernel<<<(unsigned)((nadd + 255) / 256), 256, 0, s>>>(a, tmpkv, key_base);
+      CRL_LAUNCH_CHECK("crl_attn_bwd(dK / dV of the query split)");
+    }
     const int64_t n8 = (int64_t)B * Nq * (H * 64 / 8);
     CRL_PROF_START(CRL_K_ATTN_DQ_REDUCE, stream, 0.0);
     attn_dq_reduce_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>((const u16*)ws, slab_stride, nslab, (u16*)dq, dq_bs, dq_rs, B, Nq, H * 64, a.dq_mul);

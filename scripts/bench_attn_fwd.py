@@ -61,6 +61,31 @@ def main():
         lib.crl_debug_f4w_stamps(stamps.data_ptr())
     shapes = [('vit', 8, 16, 6189, 6189), ('cross', 8, 16, 1023, 6189)]
     one = 'one' in sys.argv
+    if 'bwdtime' in sys.argv:       # the whole backward (delta + single pass + reduce) with and without the query split of the remainder chains, alternating
+        for name, B, H, Nq, Nk in (('vit', 8, 16, 6189, 6189), ('cross', 8, 16, 1023, 6189)):
+            D = H * 64
+            g = torch.Generator(device=dev).manual_seed(1)
+            qp = (torch.randn(B, Nq, D, generator=g, device=dev) * 0.125 * ops.LOG2E).to(torch.bfloat16)
+            k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(torch.bfloat16) for _ in range(2))
+            o = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=dev); lse = torch.empty(B, H, Nq, device=dev)
+            do = torch.randn(B, Nq, D, generator=g, device=dev).to(torch.bfloat16)
+            dq, dk, dv = torch.empty_like(qp), torch.empty_like(k), torch.empty_like(v)
+            delta = torch.empty(2, B, H, Nq, device=dev)
+            ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+            for rnd in range(3):
+                for split in (0, -1):
+                    hip.call('crl_attn_bwd_set_qsplit', split)
+                    run = lambda: ops.attn_bwd(qp, k, v, o, do, lse, delta, dq, dk, dv, H, 0.125, False, q_prescaled=True)
+                    for _ in range(3): run()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20): run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    print(f'{name:6s} backward, query split {"auto" if split else "off "}: {e0.elapsed_time(e1) / 20:.3f} ms', flush=True)
+            hip.call('crl_attn_bwd_set_qsplit', -1)
+        return
     if 'bwd' in sys.argv and stamps is not None:      # where the workgroups of the single-pass backward ran and when (diagnostic build)
         B, H, N = 8, 16, 6189
         D = H * 64

@@ -180,6 +180,55 @@ def test_gemm_column_scale(dev):
 
 
 # ------------------------------------------------------------------------------------------- attention backward, single-pass form
+@pytest.mark.parametrize('B,H,Nq,Nk,chain', [(1, 2, 700, 1300, 4), (2, 4, 1023, 1200, 4), (1, 8, 577, 577, 2), (1, 2, 6189, 1100, 4), (1, 1, 300, 2049, 4)])
+def test_attention_backward_query_split_of_the_remainder_chains(dev, B, H, Nq, Nk, chain):
+    """crl_attn_bwd_set_qsplit(1): the key blocks a head has left over after its full chains are walked by two workgroups of half the query tiles
+    each (the second half's dK / dV through a scratch behind the slabs + attn_bwd_addkv_kernel).  Against the unsplit launch at the same chain:
+    dQ bit for bit (rows are disjoint, same slab), dK / dV bit for bit on the key rows of the full chains and within one bf16 rounding on the
+    remainder's; twice the same bits; ragged key / query tails, strided views, B H = 8 (XCD order), a remainder of one and of two key blocks"""
+    from pixparse_amd import hip, ops
+    D, scale = H * 64, 0.125
+    g = torch.Generator(device=dev).manual_seed(Nq + 3 * Nk)
+    if Nq == Nk:
+        qkv = torch.randn(B, Nq, 3 * D, generator=g, device=dev)
+        qkv[:, :, :D] *= scale * ops.LOG2E
+        qkv = qkv.to(BF16)
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    else:
+        q = (torch.randn(B, Nq, D, generator=g, device=dev) * scale * ops.LOG2E).to(BF16)
+        k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(BF16) for _ in range(2))
+    do = torch.randn(B, Nq, D, generator=g, device=dev).to(BF16)
+    o = torch.empty(B, Nq, D, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, Nq, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False, q_prescaled=True)
+    delta = torch.empty(2, B, H, Nq, device=dev)
+
+    def bwd(split):
+        dq, dk, dv = (torch.full((B, n, D), float('nan'), dtype=BF16, device=dev) for n in (Nq, Nk, Nk))
+        hip.call('crl_attn_bwd_set_mode', 2)
+        hip.call('crl_attn_bwd_set_chain', chain)
+        hip.call('crl_attn_bwd_set_qsplit', split)
+        try:
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False, q_prescaled=True)
+        finally:
+            hip.call('crl_attn_bwd_set_mode', 0)
+            hip.call('crl_attn_bwd_set_chain', 0)
+            hip.call('crl_attn_bwd_set_qsplit', -1)
+        return dq, dk, dv
+    ref, got, again = bwd(0), bwd(1), bwd(1)
+    nkt = (Nk + 255) // 256
+    assert nkt % chain != 0, 'the shape must leave a remainder chain'
+    key_base = (nkt // chain) * chain * 256
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert torch.equal(got[0], ref[0]), 'dQ'
+    for x, y, what in ((got[1], ref[1], 'dK'), (got[2], ref[2], 'dV')):
+        assert torch.equal(x[:, :key_base], y[:, :key_base]), what + ' of the full chains'
+        assert not torch.equal(x[:, key_base:], y[:, key_base:]) or Nq < 256, what + ': the split did not run'
+        assert rel(x[:, key_base:], y[:, key_base:]) < 4e-3, (what, rel(x[:, key_base:], y[:, key_base:]))
+    for x, y in zip(got, again):
+        assert torch.equal(x, y), 'not reproducible'
+
+
 @pytest.mark.parametrize('B,H,Nq,Nk,pre', [(1, 2, 300, 700, True), (2, 1, 64, 512, True), (1, 2, 100, 45, True), (1, 2, 1023, 1300, True),
                                            (2, 2, 577, 577, True), (1, 1, 2100, 1100, True), (1, 2, 300, 700, False), (1, 1, 130, 260, False),
                                            (2, 4, 130, 600, True)])
@@ -740,9 +789,14 @@ def test_gemm_round_model_calibration(dev):
     """crl_gemm_calibrate: one / two rounds of 256x256 tiles timed at K = 1024 / 4096 on hashed bf16 operands refit the microseconds-per-round
     model of the wave-quantisation cut for THIS device.  Plausible numbers, and results of a cut GEMM unchanged."""
     from pixparse_amd import hip, ops
-    a, b, cal = ops.gemm_calibrate(dev, force=True)
-    assert cal and 0.0 <= a < 40.0 and 8.0 < b < 60.0, (a, b, cal)             # one round of 256 tiles: ~20-50 us at K = 1024 on an MI355X (a timing: wide bounds, the
-    # clock of a short launch depends on what ran before it -- 14-16 / 31-33 alone, outside 30 / 44 once in the middle of the suite)
+    seen = []
+    for attempt in range(3):        # a timing: in the middle of the suite one attempt in a few lands outside (clock ramps of the launches before it)
+        a, b, cal = ops.gemm_calibrate(dev, force=True)
+        seen.append((a, b, cal))
+        if cal and 0.0 <= a < 40.0 and 8.0 < b < 60.0:
+            break
+    assert cal and 0.0 <= a < 40.0 and 8.0 < b < 60.0, seen
+    # one round of 256 tiles: ~20-50 us at K = 1024 on an MI355X (14-16 / 31-33 when run alone)
     M, N, K = 256 * 64 + 232, 1024, 2048
     x = rnd((M, K), dev, 1.0, 1, BF16)
     w = rnd((N, K), dev, 0.05, 2, BF16)
