@@ -203,6 +203,10 @@ int crl_attn_bwd_set_chain(int chain);
  * disjoint, the second half's dK / dV go to a scratch behind the slabs and are added to the first half's by a small kernel (one more bf16 rounding on
  * those key rows).  -1 (default) = decided with the automatic chain from the simulated makespan; 0 = never; 1 = whenever legal (tests). */
 int crl_attn_bwd_set_qsplit(int mode);
+/* Single pass only: 1 (default) = when there are more chains than CUs the launch is persistent -- one workgroup per CU (minus the CUs reserved by
+ * crl_gemm_set_reserved_cus) pulls chains from the per-XCD ticket lists of the persistent GEMMs (crl_gemm_set_schedule(0) switches both to the
+ * static walk) and steals from the other XCDs' lists at the end; 0 = one workgroup per chain.  Same results either way. */
+int crl_attn_bwd_set_persistent(int on);
 /* the chain length the hand-placed single pass would use for Nk keys and BH = B * H heads under the current settings (forced chain,
  * reserved CUs); host arithmetic only */
 int crl_attn_bwd_chain_for(int Nk, int BH);

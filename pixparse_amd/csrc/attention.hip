@@ -20,6 +20,7 @@
 #include <vector>
 #include "common.h"
 #include "attn_frag.h"
+#include "gemm_common.h"      // the ticket scheduler of the persistent kernels (sched_*: the single-pass attention backward pulls its chains the same way)
 
 namespace {
 using namespace attnf;
@@ -1177,20 +1178,37 @@ __device__ unsigned long long spx_trace[6 * (SPX_TR_WG + 1) * SPX_TR_PASSES];
 // whole block time (cfg-3: 3200 key blocks over 256 CUs = 12.5 -- half the CUs walk 13), each remainder chain is run by TWO workgroups that take half
 // of the query tiles each: dQ rows are disjoint (same slab), the second half writes its dK / dV to a compact scratch [B H][rows][64] behind the slabs
 // and attn_bwd_addkv_kernel adds it to the first half's (one more bf16 rounding on those key rows).
+// PERSISTENT form (sched != nullptr): one workgroup per CU pulls its items -- chains, in the index order above -- from the ticket lists of
+// gemm_common.h: list x = the items a static launch would have placed on XCD x (x, x + 8, ...: the heads of an XCD stay on it, its L2 keeps their
+// Q / dO), a workgroup pulls from the list of the XCD it runs on and steals from the next ones once that is empty.  The XCDs of one chip differ by
+// +-3 % in speed under this kernel (profiles/r5_attn_bwd_timeline.txt): with a fixed eighth of the items each the launch ends with the slowest.
 __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, u16* __restrict__ slabs, int64_t slab_stride, int chain, int nfull, int qsplit,
-                                                                u16* __restrict__ tmpkv) {
+                                                                u16* __restrict__ tmpkv, uint32_t* __restrict__ sched, int nitems) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#if F4W_STAMPS      // diagnostic builds: entry / exit of every workgroup in 10-ns ticks + where it ran (scripts/bench_attn_fwd.py bwd timeline)
+  __shared__ int next_item;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int my_list = 0;
+  int item = blockIdx.x;
+  if (sched) {
+    if (threadIdx.x == 0) {
+      my_list = gemmc::sched_xcd();
+      next_item = gemmc::sched_resolve(sched, my_list, gemmc::sched_pull(sched + my_list), nitems);
+    }
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(next_item);
+  }
+ bool sched_started = false;      // a second item of this workgroup: the LDS is still the previous stream's until every wave has left it
+ for (; item >= 0 && item < nitems;) {
+#if F4W_STAMPS      // diagnostic builds: entry / exit of every item in 10-ns ticks + where it ran (scripts/bench_attn_fwd.py bwd timeline)
   const unsigned long long dbg_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // longest first: the nfull = nkt / chain full chains of every (batch, head), then the remainders (workgroups start in index order, so
+  // longest first: the nfull = nkt / chain full chains of every (batch, head), then the remainders (items start in index order, so
   // the short ones fill the last round)
   int bh, cidx, qhalf = -1;
   const int nfull_wg = nfull * a.B * a.H;
-  if ((int)blockIdx.x < nfull_wg) block_to_bh_tile(blockIdx.x, nfull, a.B * a.H, bh, cidx);
-  else if (!qsplit) { block_to_bh_tile(blockIdx.x - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
-  else { block_to_bh_tile(blockIdx.x - nfull_wg, 2, a.B * a.H, bh, qhalf); cidx = nfull; }
+  if (item < nfull_wg) block_to_bh_tile(item, nfull, a.B * a.H, bh, cidx);
+  else if (!qsplit) { block_to_bh_tile(item - nfull_wg, 1, a.B * a.H, bh, cidx); cidx = nfull; }
+  else { block_to_bh_tile(item - nfull_wg, 2, a.B * a.H, bh, qhalf); cidx = nfull; }
   const int b = bh / a.H, h = bh % a.H;
   const int HD2 = a.H * 64 * 2;                    // bytes per slab row
   // the query rows this workgroup walks: all of them, or one half of the 64-query tiles (query split of a remainder chain)
@@ -1263,7 +1281,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
     uint32_t s_tmp1, s_cnt;
 
     // every wave has left the previous key block's stream (its last LDS reads are behind a full wait): the LDS is free
-    if (kblk != cidx * chain) __syncthreads();
+    if (kblk != cidx * chain || sched_started) __syncthreads();
     // K of the whole workgroup -> LDS (rows past Nk arrive as zeros: whatever dS the clamped fragments of such keys produce, it meets a
     // zero K^T row in dQ), query tiles 0 and 1 -> ring slots 0 and 1, the running partials of tiles 0 and 1 -> partial buffers 0 and 1
 #pragma unroll
@@ -1300,12 +1318,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
   }
 #if F4W_STAMPS
   if (g_f4w_stamps && threadIdx.x == 0) {
-    g_f4w_stamps[4 * blockIdx.x] = (unsigned long long)(kb_end - cidx * chain);      // key blocks of this chain
-    g_f4w_stamps[4 * blockIdx.x + 1] = dbg_rt0;
-    g_f4w_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-    g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    g_f4w_stamps[4 * item] = (unsigned long long)(kb_end - cidx * chain);      // key blocks of this chain
+    g_f4w_stamps[4 * item + 1] = dbg_rt0;
+    g_f4w_stamps[4 * item + 2] = __builtin_amdgcn_s_memrealtime();
+    g_f4w_stamps[4 * item + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
   }
 #endif
+  sched_started = true;
+  if (sched) {
+    __syncthreads();      // every wave has read next_item of the previous round (and left the stream)
+    if (threadIdx.x == 0) next_item = gemmc::sched_resolve(sched, my_list, gemmc::sched_pull(sched + my_list), nitems);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(next_item);
+  } else {
+    item += gridDim.x;
+  }
+ }
+  if (sched && threadIdx.x == 0) gemmc::sched_leave(sched, gridDim.x);
 }
 
 // query split of the remainder chains: dk / dv rows key_base .. Nk - 1 (+)= the second half's compact partials; 16 bytes per thread and array
@@ -1484,6 +1513,8 @@ int crl_gemm_cus();              // gemm.hip: CUs not set aside for RCCL (crl_ge
 // The workgroups start longest first -- nfull = nkt / c full chains per head, then the remainders --; the makespan of that order on the
 // available CUs is simulated once per (nkt, heads, CUs) and the cheapest c kept.  Same-box A/B at cfg-3 (25 key blocks, 128 heads):
 // c = 3 / 4 / 6 within noise of each other, -2.5 ms per step against c = 1, c = 12 half of that (profiles/r4_attn_chain.txt).
+static int g_bwd_persist = 1;      // the hand-placed single pass as a persistent launch that pulls its chains from ticket lists (0: one workgroup per chain)
+extern "C" int crl_attn_bwd_set_persistent(int on) { g_bwd_persist = on != 0; return 0; }
 static int g_bwd_qsplit = -1;      // query split of the remainder chains: -1 auto (with the automatic chain only), 0 off, 1 whenever legal
 extern "C" int crl_attn_bwd_set_qsplit(int mode) {
   if (mode < -1 || mode > 1) { crl_set_error("crl_attn_bwd_set_qsplit: -1 auto, 0 off, 1 whenever legal"); return -1; }
@@ -1667,7 +1698,18 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     const unsigned grid_spx = (unsigned)(nfull + (nchain > nfull ? (qsplit ? 2 : 1) : 0)) * B * H;
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
-    if (spx) attn_bwd_spx_kernel<<<grid_spx, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull, qsplit ? 1 : 0, tmpkv);
+    if (spx) {
+      // persistent when there are more items than CUs to spread over and the tile tickets are on (crl_gemm_set_schedule); the slot ring of this stream
+      uint32_t* sched = nullptr;
+      unsigned launch = grid_spx;
+      if (crl_gemm_dynamic() && g_bwd_persist && (int)grid_spx > crl_gemm_cus()) {
+        bool ok;
+        sched = crl_sched_slot(s, &ok);
+        if (!ok) return -2;
+        if (sched) launch = (unsigned)crl_gemm_cus();
+      }
+      attn_bwd_spx_kernel<<<launch, 256, SPX_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull, qsplit ? 1 : 0, tmpkv, sched, (int)grid_spx);
+    }
     else if (q_prescaled) attn_bwd_sp_kernel<true><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
     else attn_bwd_sp_kernel<false><<<(unsigned)nchain * B * H, 256, SP_LDS, s>>>(a, (u16*)ws, slab_stride, chain, nfull);
     CRL_PROF_STOP(CRL_K_ATTN_BWD_FUSED, stream);

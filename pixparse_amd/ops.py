@@ -290,6 +290,8 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, heads: int, scale: float, 
             hip.call('crl_attn_bwd_set_mode', int(os.environ['PIXPARSE_AMD_ATTN_BWD_MODE']))
         if os.environ.get('PIXPARSE_AMD_ATTN_BWD_QSPLIT'):  # query split of the single pass's remainder chains (crl_attn_bwd_set_qsplit; -1 = auto)
             hip.call('crl_attn_bwd_set_qsplit', int(os.environ['PIXPARSE_AMD_ATTN_BWD_QSPLIT']))
+        if os.environ.get('PIXPARSE_AMD_ATTN_BWD_PERSIST'):  # 0: one workgroup per chain instead of the persistent ticket-pulling launch (crl_attn_bwd_set_persistent)
+            hip.call('crl_attn_bwd_set_persistent', int(os.environ['PIXPARSE_AMD_ATTN_BWD_PERSIST']))
         if os.environ.get('PIXPARSE_AMD_ATTN_BWD_CHAIN'):   # key blocks per workgroup of the single pass (crl_attn_bwd_set_chain; 0 = auto)
             hip.call('crl_attn_bwd_set_chain', int(os.environ['PIXPARSE_AMD_ATTN_BWD_CHAIN']))
     B, Nq, _ = q.shape

@@ -73,8 +73,9 @@ def main():
             delta = torch.empty(2, B, H, Nq, device=dev)
             ops.attn_fwd(qp, k, v, o, lse, H, 0.125, False, q_prescaled=True)
             for rnd in range(3):
-                for split in (0, -1):
+                for split, persist in ((0, 0), (-1, 0), (-1, 1)):
                     hip.call('crl_attn_bwd_set_qsplit', split)
+                    hip.call('crl_attn_bwd_set_persistent', persist)
                     run = lambda: ops.attn_bwd(qp, k, v, o, do, lse, delta, dq, dk, dv, H, 0.125, False, q_prescaled=True)
                     for _ in range(3): run()
                     torch.cuda.synchronize()
@@ -83,8 +84,9 @@ def main():
                     for _ in range(20): run()
                     e1.record()
                     torch.cuda.synchronize()
-                    print(f'{name:6s} backward, query split {"auto" if split else "off "}: {e0.elapsed_time(e1) / 20:.3f} ms', flush=True)
+                    print(f'{name:6s} backward, query split {"auto" if split else "off "}, {"persistent (tickets)" if persist else "one workgroup per chain"}: {e0.elapsed_time(e1) / 20:.3f} ms', flush=True)
             hip.call('crl_attn_bwd_set_qsplit', -1)
+            hip.call('crl_attn_bwd_set_persistent', 1)
         return
     if 'bwd' in sys.argv and stamps is not None:      # where the workgroups of the single-pass backward ran and when (diagnostic build)
         B, H, N = 8, 16, 6189

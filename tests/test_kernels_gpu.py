@@ -229,6 +229,51 @@ def test_attention_backward_query_split_of_the_remainder_chains(dev, B, H, Nq, N
         assert torch.equal(x, y), 'not reproducible'
 
 
+@pytest.mark.parametrize('chain', [1, 4])
+def test_attention_backward_persistent_launch_pulls_the_same_chains(dev, chain):
+    """crl_attn_bwd_set_persistent: with more chains than CUs (here: all but 32 CUs reserved) the single pass is launched as one workgroup per CU that
+    pulls its chains from the per-XCD ticket lists and steals at the end -- bit-identical to one workgroup per chain, with and without the query
+    split, and to the static walk (crl_gemm_set_schedule(0)); forty launches through the slot ring leave the counters zeroed"""
+    from pixparse_amd import hip, ops
+    B, H, Nq, Nk = 2, 8, 577, 1300
+    D, scale = H * 64, 0.125
+    g = torch.Generator(device=dev).manual_seed(7)
+    q = (torch.randn(B, Nq, D, generator=g, device=dev) * scale * ops.LOG2E).to(BF16)
+    k, v = (torch.randn(B, Nk, D, generator=g, device=dev).to(BF16) for _ in range(2))
+    do = torch.randn(B, Nq, D, generator=g, device=dev).to(BF16)
+    o = torch.empty(B, Nq, D, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, Nq, device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False, q_prescaled=True)
+    delta = torch.empty(2, B, H, Nq, device=dev)
+
+    def bwd(persist, dynamic=True):
+        dq, dk, dv = (torch.full((B, n, D), float('nan'), dtype=BF16, device=dev) for n in (Nq, Nk, Nk))
+        hip.call('crl_attn_bwd_set_persistent', persist)
+        ops.gemm_set_schedule(dynamic)
+        ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, H, scale, False, q_prescaled=True)
+        return dq, dk, dv
+    try:
+        hip.call('crl_attn_bwd_set_mode', 2)
+        hip.call('crl_attn_bwd_set_chain', chain)
+        hip.call('crl_attn_bwd_set_qsplit', 1)
+        ops.gemm_set_reserved_cus(224)
+        want = bwd(0)
+        for rep in range(40):
+            got = bwd(1)
+            if rep in (0, 39):
+                for x, y in zip(got, want):
+                    assert torch.equal(x, y), f'persistent launch differs (rep {rep})'
+        for x, y in zip(bwd(1, dynamic=False), want):
+            assert torch.equal(x, y), 'static walk differs'
+    finally:
+        ops.gemm_set_reserved_cus(0)
+        ops.gemm_set_schedule(True)
+        hip.call('crl_attn_bwd_set_persistent', 1)
+        hip.call('crl_attn_bwd_set_qsplit', -1)
+        hip.call('crl_attn_bwd_set_chain', 0)
+        hip.call('crl_attn_bwd_set_mode', 0)
+
+
 @pytest.mark.parametrize('B,H,Nq,Nk,pre', [(1, 2, 300, 700, True), (2, 1, 64, 512, True), (1, 2, 100, 45, True), (1, 2, 1023, 1300, True),
                                            (2, 2, 577, 577, True), (1, 1, 2100, 1100, True), (1, 2, 300, 700, False), (1, 1, 130, 260, False),
                                            (2, 4, 130, 600, True)])
