@@ -189,6 +189,9 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
  * and 512 = one per CU.  crl_attn_fwd_set_mode: 0 = auto (default), 1 = the 32-queries-per-wave kernels everywhere, 2 = the stream with its
  * fallback forced on every block (tests), 3 = the 512-register form, 4 = the 256-register form. */
 int crl_attn_fwd_set_mode(int mode);
+/* 1 (default): with more query blocks than workgroup slots the stream is launched persistently and pulls its blocks from the per-XCD ticket lists
+ * (as crl_attn_bwd_set_persistent); 0 = one workgroup per block.  Same results. */
+int crl_attn_fwd_set_persistent(int on);
 size_t crl_attn_bwd_ws_bytes(int B, int H, int Nq, int Nk, int causal);
 int crl_attn_bwd_set_mode(int mode);
 /* Single pass only: key blocks per workgroup.  A workgroup walks `chain` consecutive 256-key blocks of its (batch, head) and adds each

@@ -448,17 +448,30 @@ __device__ unsigned long long* g_f4w_stamps = nullptr;
 // behind their last use, MFMA-only operands in the accumulator half) so that TWO workgroups share a CU: a lone wave issues its v_exp, conversions, LDS
 // reads and MFMAs strictly one after the other (~1500 issue cycles per key tile against 1152 of matrix-pipe time), two waves per SIMD overlap them.
 template <int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, int force_fallback) {
+// sched != nullptr: persistent -- the resident workgroups pull their query blocks from the per-XCD ticket lists of gemm_common.h (see attn_bwd_spx_kernel)
+__global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, int force_fallback, uint32_t* __restrict__ sched, int nitems) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
-#if F4W_STAMPS
-  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  __shared__ int next_item;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31, hh = lane >> 5;
   const int nqb = (a.Nq + 255) / 256;
+  int my_list = 0;
+  int item = blockIdx.x;
+  if (sched) {
+    if (tid == 0) {
+      my_list = gemmc::sched_xcd();
+      next_item = gemmc::sched_resolve(sched, my_list, gemmc::sched_pull(sched + my_list), nitems);
+    }
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(next_item);
+  }
+ for (; item >= 0 && item < nitems;) {
+#if F4W_STAMPS
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int bh, qt;
-  block_to_bh_tile(blockIdx.x, nqb, a.B * a.H, bh, qt);
+  block_to_bh_tile(item, nqb, a.B * a.H, bh, qt);
   const int b = bh / a.H, h = bh % a.H;
 
   const u16* qp = a.q + b * a.q_bs + h * 64;
@@ -554,10 +567,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
 #if F4W_STAMPS
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     if (g_f4w_stamps && tid == 0) {      // [0] stream cycles, [1] / [2] entry of the kernel / end of the stream in 10-ns ticks (s_memrealtime), [3] HW_ID | XCC_ID << 32
-      g_f4w_stamps[4 * blockIdx.x] = st1 - st0;
-      g_f4w_stamps[4 * blockIdx.x + 1] = rt0;
-      g_f4w_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-      g_f4w_stamps[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+      g_f4w_stamps[4 * item] = st1 - st0;
+      g_f4w_stamps[4 * item + 1] = rt0;
+      g_f4w_stamps[4 * item + 2] = __builtin_amdgcn_s_memrealtime();
+      g_f4w_stamps[4 * item + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                          ((rt1 - rt0) << 40);      // bits 40..: ticks from kernel entry to the stream's first instruction (prologue)
     }
 #endif
@@ -609,7 +622,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd4w_kernel(const AttnArgs a, 
     fwd_pre_block<false, false>(a, smem4, bh, 2 * qt);
     __syncthreads();
     if ((2 * qt + 1) * 128 < a.Nq) fwd_pre_block<false, false>(a, smem4, bh, 2 * qt + 1);
+    __syncthreads();
   }
+  if (sched) {
+    if (tid == 0) next_item = gemmc::sched_resolve(sched, my_list, gemmc::sched_pull(sched + my_list), nitems);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(next_item);
+    __syncthreads();      // next_item may be rewritten only after every wave has read it
+  } else {
+    item += gridDim.x;
+  }
+ }
+  if (sched && tid == 0) gemmc::sched_leave(sched, gridDim.x);
 }
 
 // ======================================================================================= delta = rowsum(dO * O)
@@ -1430,6 +1454,8 @@ extern "C" int crl_debug_f4w_stamps(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_f4w_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
 #endif
+static int g_fwd_persist = 1;      // the forward stream as a persistent launch pulling query blocks from ticket lists (0: one workgroup per block)
+extern "C" int crl_attn_fwd_set_persistent(int on) { g_fwd_persist = on != 0; return 0; }
 static int g_fwd_mode = 0;      // 0 auto (hand-placed stream where it applies), 1 the 32-queries-per-wave kernels only, 2 stream + forced fallback, 3 / 4 stream with one / two waves per SIMD
 extern "C" int crl_attn_fwd_set_mode(int mode) {
   if (mode < 0 || mode > 4) { crl_set_error("crl_attn_fwd_set_mode: 0 auto, 1 compiler-scheduled kernels only, 2 hand-placed stream with its fallback forced (tests), 3 / 4 the stream with one / two waves per SIMD"); return -1; }
@@ -1474,8 +1500,19 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
       configured = true;
     }
     const unsigned g4 = (unsigned)((Nq + 255) / 256) * B * H;
-    if (g_fwd_mode == 3 || !F4W_OCC2) attn_fwd4w_kernel<1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
-    else attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1><<<g4, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2);
+    const bool one_per_cu = g_fwd_mode == 3 || !F4W_OCC2;
+    // persistent when there are more query blocks than workgroup slots: the resident workgroups pull blocks from the per-XCD ticket lists
+    uint32_t* sched = nullptr;
+    unsigned launch = g4;
+    const unsigned slots = (unsigned)crl_gemm_cus() * (one_per_cu ? 1u : 2u);
+    if (crl_gemm_dynamic() && g_fwd_persist && g4 > slots) {
+      bool ok;
+      sched = crl_sched_slot(as_stream(stream), &ok);
+      if (!ok) return -2;
+      if (sched) launch = slots;
+    }
+    if (one_per_cu) attn_fwd4w_kernel<1><<<launch, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2, sched, (int)g4);
+    else attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1><<<launch, 256, F4W_LDS, as_stream(stream)>>>(a, g_fwd_mode == 2, sched, (int)g4);
   } else if (q_prescaled) {       // base-2 logits straight from the MFMAs: the seeded / lazy-maximum kernel (`scale` is not used)
     if (drop) { if (causal) attn_fwd_pre_kernel<true, true><<<grid, 256, 0, as_stream(stream)>>>(a); else attn_fwd_pre_kernel<false, true><<<grid, 256, 0, as_stream(stream)>>>(a); }
     else if (causal) attn_fwd_pre_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a);

@@ -49,6 +49,7 @@ SIGNATURES = {
                          I, I, I, I, F, I, I, F, U64, U32, U32, P, Z, P]),
     'crl_attn_bwd_ws_bytes': (Z, [I, I, I, I, I]),
     'crl_attn_fwd_set_mode': (I, [I]),
+    'crl_attn_fwd_set_persistent': (I, [I]),
     'crl_attn_bwd_set_mode': (I, [I]),
     'crl_attn_bwd_set_parts': (I, [I]),
     'crl_attn_bwd_set_chain': (I, [I]),

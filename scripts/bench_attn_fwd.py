@@ -45,7 +45,7 @@ def timeline(rec, what, per_wg=True):
           f'median CU\'s last start {sorted(last_start)[len(last_start) // 2] / 100:.1f} us', flush=True)
 
 
-NAMES = {0: 'stream, 1 wave / SIMD  ', 1: '32 q per wave          ', 4: 'stream, 2 waves / SIMD '}
+NAMES = {0: 'stream (default)       ', 1: '32 q per wave          ', 4: 'stream, 2 waves / SIMD ', 5: 'stream, not persistent '}
 
 
 def main():
@@ -125,8 +125,9 @@ def main():
         fl = 4.0 * Nq * Nk * 64 * B * H
         ref = None
         for rnd in range(1 if one else 3):
-            for mode in ((0, 4) if one else (1, 0, 4)):
-                hip.call('crl_attn_fwd_set_mode', mode)
+            for mode in ((0, 4) if one else ((1, 0, 5) if 'persist' in sys.argv else (1, 0, 4))):
+                hip.call('crl_attn_fwd_set_mode', 0 if mode == 5 else mode)
+                hip.call('crl_attn_fwd_set_persistent', 0 if mode == 5 else 1)
                 if mode == 4 and os.environ.get('F4W_OCC2', '0') != '1':
                     continue
                 for _ in range(5):
@@ -155,6 +156,7 @@ def main():
                     extra += f'  stream cycles per workgroup: mean {float(st.mean()):.0f} min {float(st.min()):.0f} max {float(st.max()):.0f} = {float(st.mean()) / ((Nk + 63) // 64):.0f} per key tile'
                 print(f'{name:6s} B{B} H{H} Nq{Nq} Nk{Nk} round {rnd} {NAMES[mode]}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s{extra}', flush=True)
         hip.call('crl_attn_fwd_set_mode', 0)
+        hip.call('crl_attn_fwd_set_persistent', 1)
 
 
 if __name__ == '__main__':

@@ -124,6 +124,42 @@ def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
     close(res[0][0], ref, 2e-2, 2e-2, 'stream out')
 
 
+def test_attention_fwd_persistent_launch_pulls_the_same_blocks(dev):
+    """crl_attn_fwd_set_persistent: with more query blocks than workgroup slots (all but 32 CUs reserved: 64 slots) the stream is launched persistently and
+    pulls its blocks from the per-XCD ticket lists -- bit-identical to one workgroup per block, also with the static walk and in the one-per-CU form;
+    forty launches through the slot ring leave the counters zeroed"""
+    from pixparse_amd import hip, ops
+    B, H, Nq, Nk = 2, 8, 1500, 1000          # 6 query blocks x 16 heads = 96 items
+    D = H * 64
+    g = torch.Generator(device=dev).manual_seed(11)
+    qpre = (torch.randn(B, Nq, D, generator=g, device=dev) * 0.125 * ops.LOG2E * 2.0).to(BF16)
+    k = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+    v = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+
+    def fwd(persist, mode=0, dynamic=True):
+        hip.call('crl_attn_fwd_set_persistent', persist)
+        hip.call('crl_attn_fwd_set_mode', mode)
+        ops.gemm_set_schedule(dynamic)
+        o = torch.full_like(qpre, float('nan'))
+        lse = torch.full((B, H, Nq), float('nan'), device=dev)
+        ops.attn_fwd(qpre, k, v, o, lse, H, 0.125, False, q_prescaled=True)
+        return o, lse
+    try:
+        ops.gemm_set_reserved_cus(224)
+        want = fwd(0)
+        for rep in range(40):
+            got = fwd(1)
+            if rep in (0, 39):
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), f'persistent launch differs (rep {rep})'
+        for got in (fwd(1, dynamic=False), fwd(1, mode=3), fwd(0, mode=3)):
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    finally:
+        ops.gemm_set_reserved_cus(0)
+        ops.gemm_set_schedule(True)
+        hip.call('crl_attn_fwd_set_persistent', 1)
+        hip.call('crl_attn_fwd_set_mode', 0)
+
+
 def test_attention_fwd_stream_overflow_falls_back(dev):
     """rows whose later scores exceed the first key tile's maximum by more than 2^127 (and rows that stay far below it) -- the stream's fixed
     reference overflows, the workgroup re-runs the block with the moving maximum: finite and right; moderate growth (2^60) stays in line"""
