@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm backward
 // each wave walks rows (grid-stride); dgamma/dbeta partials stay in registers, are combined over
 // the block's 4 waves through LDS and written to ws[block][2][D]; ln_bwd_reduce sums the blocks.
-constexpr int LNB_MAXBLK = 512;
+#ifndef LNB_MAXBLK_N
+#define LNB_MAXBLK_N 512
+#endif
+constexpr int LNB_MAXBLK = LNB_MAXBLK_N;
 
 // NV = float4 slots per lane (4: D <= 1024, 8: D <= 2048), COLSUM = also emit the column sums of dx16.  Both are compile-time so the
 // D = 1024 rows of the step keep ~110 VGPRs (4 waves / SIMD); with 8 slots and a run-time colsum flag the kernel sat at 2 waves /
