@@ -1505,7 +1505,8 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     uint32_t* sched = nullptr;
     unsigned launch = g4;
     const unsigned slots = (unsigned)crl_gemm_cus() * (one_per_cu ? 1u : 2u);
-    if (crl_gemm_dynamic() && g_fwd_persist && g4 > slots) {
+    // (worth the ticket round trips from four blocks per slot on: at cfg-2's 1.9 the persistent form measured 18 us per launch slower)
+    if (crl_gemm_dynamic() && g_fwd_persist && g4 >= 4 * slots) {
       bool ok;
       sched = crl_sched_slot(as_stream(stream), &ok);
       if (!ok) return -2;
@@ -1736,10 +1737,11 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
     const double pairs_f = (double)Nq * Nk;
     CRL_PROF_START(CRL_K_ATTN_BWD_FUSED, stream, 8.0 * 64 * pairs_f * B * H);      // the WHOLE algorithmic backward (dV, dP, dK, dQ)
     if (spx) {
-      // persistent when there are more items than CUs to spread over and the tile tickets are on (crl_gemm_set_schedule); the slot ring of this stream
+      // persistent from three items per CU on (fewer: nothing to balance, only ticket round trips to pay) when the tile tickets are on
+      // (crl_gemm_set_schedule); the slot ring of this stream
       uint32_t* sched = nullptr;
       unsigned launch = grid_spx;
-      if (crl_gemm_dynamic() && g_bwd_persist && (int)grid_spx > crl_gemm_cus()) {
+      if (crl_gemm_dynamic() && g_bwd_persist && (int)grid_spx >= 3 * crl_gemm_cus()) {
         bool ok;
         sched = crl_sched_slot(s, &ok);
         if (!ok) return -2;

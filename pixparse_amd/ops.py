@@ -241,6 +241,8 @@ def attn_fwd(q, k, v, o, lse, heads: int, scale: float, causal: bool, drop=None,
         _attn_fwd_env_applied = True
         if os.environ.get('PIXPARSE_AMD_ATTN_FWD_MODE'):
             hip.call('crl_attn_fwd_set_mode', int(os.environ['PIXPARSE_AMD_ATTN_FWD_MODE']))
+        if os.environ.get('PIXPARSE_AMD_ATTN_FWD_PERSIST'):     # 0: one workgroup per query block instead of the persistent launch
+            hip.call('crl_attn_fwd_set_persistent', int(os.environ['PIXPARSE_AMD_ATTN_FWD_PERSIST']))
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _chk_heads(heads, q, k, v, o)

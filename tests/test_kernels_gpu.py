@@ -129,7 +129,7 @@ def test_attention_fwd_persistent_launch_pulls_the_same_blocks(dev):
     pulls its blocks from the per-XCD ticket lists -- bit-identical to one workgroup per block, also with the static walk and in the one-per-CU form;
     forty launches through the slot ring leave the counters zeroed"""
     from pixparse_amd import hip, ops
-    B, H, Nq, Nk = 2, 8, 1500, 1000          # 6 query blocks x 16 heads = 96 items
+    B, H, Nq, Nk = 4, 8, 2100, 600           # 9 query blocks x 32 heads = 288 items for 64 slots (32 CUs in the one-per-CU form)
     D = H * 64
     g = torch.Generator(device=dev).manual_seed(11)
     qpre = (torch.randn(B, Nq, D, generator=g, device=dev) * 0.125 * ops.LOG2E * 2.0).to(BF16)
@@ -271,7 +271,7 @@ def test_attention_backward_persistent_launch_pulls_the_same_chains(dev, chain):
     pulls its chains from the per-XCD ticket lists and steals at the end -- bit-identical to one workgroup per chain, with and without the query
     split, and to the static walk (crl_gemm_set_schedule(0)); forty launches through the slot ring leave the counters zeroed"""
     from pixparse_amd import hip, ops
-    B, H, Nq, Nk = 2, 8, 577, 1300
+    B, H, Nq, Nk = 4, 8, 577, 2600          # 11 key blocks x 32 heads: 352 chains of one, (2 + 2) x 32 = 128 items at chain 4 with the split, for 32 CUs
     D, scale = H * 64, 0.125
     g = torch.Generator(device=dev).manual_seed(7)
     q = (torch.randn(B, Nq, D, generator=g, device=dev) * scale * ops.LOG2E).to(BF16)
