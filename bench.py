@@ -398,7 +398,8 @@ def main():
             if m.enc_kind == 'vit':     # key blocks per workgroup of the single-pass attention backward (DESIGN.md "Chains of key blocks")
                 from pixparse_amd import hip as _hip
                 enc0 = m._engines[0]
-                live_prof['attn_bwd_chain'] = {'key_blocks': (enc0.N + 255) // 256, 'chain': _hip.query('crl_attn_bwd_chain_for', enc0.N, args.batch * enc0.heads)}
+                live_prof['attn_bwd_chain'] = {'key_blocks': (enc0.N + 255) // 256, 'chain': _hip.query('crl_attn_bwd_chain_for', enc0.N, args.batch * enc0.heads),
+                                            'remainder_split_by_query_halves': bool(_hip.query('crl_attn_bwd_qsplit_for', enc0.N, args.batch * enc0.heads))}
             # everything that is not an attention launch (GEMMs, LayerNorm, loss, optimiser, gaps): the line VERDICT r3 asked to watch
             att_ms = sum(k['ms_per_step'] for k in live_prof['kernels'].values())
             out['non_attention_ms_per_step'] = round(out['ms_per_step'] - att_ms, 2)

@@ -206,6 +206,8 @@ int crl_attn_bwd_set_chain(int chain);
  * disjoint, the second half's dK / dV go to a scratch behind the slabs and are added to the first half's by a small kernel (one more bf16 rounding on
  * those key rows).  -1 (default) = decided with the automatic chain from the simulated makespan; 0 = never; 1 = whenever legal (tests). */
 int crl_attn_bwd_set_qsplit(int mode);
+/* 1 when the hand-placed single pass would split the remainder chains for Nk keys and BH = B * H heads under the current settings; host arithmetic only */
+int crl_attn_bwd_qsplit_for(int Nk, int BH);
 /* Single pass only: 1 (default) = when there are more chains than CUs the launch is persistent -- one workgroup per CU (minus the CUs reserved by
  * crl_gemm_set_reserved_cus) pulls chains from the per-XCD ticket lists of the persistent GEMMs (crl_gemm_set_schedule(0) switches both to the
  * static walk) and steals from the other XCDs' lists at the end; 0 = one workgroup per chain.  Same results either way. */

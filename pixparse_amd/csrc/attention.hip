@@ -1637,6 +1637,13 @@ static int bwd_chain_length(int nkt, int BH, bool stream, int* qsplit = nullptr)
   memo_n = memo_n < 8 ? memo_n + 1 : 8;
   return best_c;
 }
+// whether crl_attn_bwd would split the remainder chains of that problem between two workgroups by query halves (pure host arithmetic)
+extern "C" int crl_attn_bwd_qsplit_for(int Nk, int BH) {
+  if (Nk <= 0 || BH <= 0) { crl_set_error("crl_attn_bwd_qsplit_for: empty problem"); return -1; }
+  int split = 0;
+  const int nkt = (Nk + 255) / 256, c = bwd_chain_length(nkt, BH, true, &split);
+  return (split && nkt % c != 0) ? 1 : 0;
+}
 // the chain length crl_attn_bwd would use for Nk keys and B * H heads right now (pure host arithmetic: no GPU needed)
 extern "C" int crl_attn_bwd_chain_for(int Nk, int BH) {
   if (Nk <= 0 || BH <= 0) { crl_set_error("crl_attn_bwd_chain_for: empty problem"); return -1; }

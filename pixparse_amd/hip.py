@@ -54,6 +54,7 @@ SIGNATURES = {
     'crl_attn_bwd_set_parts': (I, [I]),
     'crl_attn_bwd_set_chain': (I, [I]),
     'crl_attn_bwd_set_qsplit': (I, [I]),
+    'crl_attn_bwd_qsplit_for': (I, [I, I]),
     'crl_attn_bwd_set_persistent': (I, [I]),
     'crl_attn_bwd_chain_for': (I, [I, I]),
     'crl_debug_occupy_cus': (I, [I, ctypes.c_double, P, P]),

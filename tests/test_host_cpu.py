@@ -569,6 +569,34 @@ def test_attention_backward_chain_length_follows_the_available_cus():
     assert q(6189, 128) == 4
 
 
+def test_attention_backward_query_split_follows_the_simulated_makespan():
+    """crl_attn_bwd_qsplit_for: the key blocks a head has left over after its full chains are split between two workgroups (by query halves) when that
+    shortens the simulated makespan by at least half a key block.  cfg-3 (25 key blocks, 128 heads, chains of 4): 768 chains fill 256 CUs three times,
+    the 128 one-block remainders would give half the CUs a 13th block -- 256 half blocks give every CU 12.5: split.  cfg-2 (10 key blocks, 96 heads,
+    chains of 4 + a remainder of 2): the remainders already fit beside the last full chains, nothing to gain.  No remainder, a forced chain (then only
+    with qsplit forced too) and crl_attn_bwd_set_qsplit(0): no split.  Host arithmetic only."""
+    from pixparse_amd import hip
+    s = lambda nk, bh: hip.query('crl_attn_bwd_qsplit_for', nk, bh)
+    try:
+        assert s(6189, 128) == 1
+        assert s(2401, 96) == 0
+        assert s(1024, 128) == 0                                      # four key blocks, one chain of four: no remainder
+        hip.call('crl_attn_bwd_set_qsplit', 0)
+        assert s(6189, 128) == 0
+        hip.call('crl_attn_bwd_set_qsplit', -1)
+        hip.call('crl_attn_bwd_set_chain', 4)                         # forced chain: the automatic split is off ...
+        assert s(6189, 128) == 0
+        hip.call('crl_attn_bwd_set_qsplit', 1)                        # ... unless forced too
+        assert s(6189, 128) == 1 and s(1024, 128) == 0
+        with pytest.raises(hip.HipLibraryError):
+            hip.call('crl_attn_bwd_set_qsplit', 2)
+        assert hip.query('crl_attn_bwd_qsplit_for', 0, 4) == -1
+    finally:
+        hip.call('crl_attn_bwd_set_qsplit', -1)
+        hip.call('crl_attn_bwd_set_chain', 0)
+    assert s(6189, 128) == 1
+
+
 def test_bucketed_reducer_two_gloo_ranks():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
