@@ -52,22 +52,16 @@ enum { CRL_EPI_BF16 = 0, CRL_EPI_BF16_GELU = 1, CRL_EPI_BF16_DGELU = 2, CRL_EPI_
  * layouts use it for the few remainder rows of the wave-quantisation split when K >= 2048 (0 = not needed). */
 size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K);
 /* kernel selection override for tests / A-B runs: 0 = auto (the 256-row kernels when they fill the chip, else 128x128),
- * 1 = always 128x128, 2 = 256x256 (8 waves, one workgroup per CU) whenever legal, 3 = 256x128 (4 waves, two independent
- * workgroups per CU: epilogues overlap main loops) for the NT / NN layouts whenever legal. */
+ * 1 = always 128x128, 2 = a 256x256 kernel (one workgroup per CU; which one: crl_gemm_set_big_kernel) whenever legal. */
 int crl_gemm_set_policy(int policy);
 /* which 256x256 kernel serves the big launches: 2 (default) = per launch -- the 4-wave one-wave-per-SIMD kernel with the hand-placed main loop
  * (gemm4w.hip, round 5) where a workgroup walks >= 32 K tiles behind a store-only epilogue (weight gradients, long-K dgrads), else the 8-wave
  * 8-phase kernel (gemm256.hip); 1 / 0 force one of them.  Same results bit for bit; tests / same-box A-B.  Process-wide. */
 int crl_gemm_set_big_kernel(int which);
 /* 1 (default): plain-bf16 NT / NN launches of the 4-wave kernel with whole column tiles and at least three rounds of tiles run the epilogue of output
- * tile T inside the main loop of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles; bit 1 (2 | 3): also the
- * fp32-residual epilogue (measured slower, off); 7: both forms for ANY number of tiles (tests).  Same results bit for bit.  Process-wide. */
+ * tile T inside the main loop of tile T + 1 (gemm4w.hip, overlapped form); 0: the classic epilogue between the tiles; 7: the overlapped form for
+ * ANY number of tiles (tests).  Same results bit for bit.  Process-wide. */
 int crl_gemm_set_overlap(int on);
-/* 1 (default 0: measured slower, profiles/r5_gemm_async_xcd.txt): the remainder rows of a wave-quantisation cut (NT / NN launches whose last round of 256x256 tiles would be less than 60 % full) run
- * BESIDE the persistent launch on a side stream of the library, forked from / joined to the caller's stream by events around the two launches
- * (never while the caller's stream is being captured); 0: the round-3 cost model and serial launches.  Which rows take which kernel depends
- * on this switch and on the problem only, never on a timing.  Process-wide. */
-int crl_gemm_set_async_remainder(int on);
 /* tuning aid for the wave-quantisation cut (gemm.hip quant_rows): multiplies the modelled cost of the remainder launch (default 1);
    < 0 = never cut.  Process-wide. */
 int crl_gemm_set_quant_cost(float c);

@@ -17,6 +17,7 @@
 // ds_read_b128 row reads and the transposed reads.
 #include <algorithm>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "attn_frag.h"
@@ -1491,14 +1492,8 @@ extern "C" int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (q_prescaled && !drop && !causal && g_fwd_mode != 1 && Nk >= 128 && (uint64_t)(Nq + 64) * (uint64_t)q_rs * 2 < (1ull << 32)) {
     // the hand-placed stream: 256 queries per workgroup, two workgroups per CU (mode 3: the 512-register form, one per CU; mode 2: every block also
     // runs its moving-maximum fallback -- tests)
-    static bool configured = false;
-    if (!configured) {
-      for (const void* f : {reinterpret_cast<const void*>(&attn_fwd4w_kernel<1>), reinterpret_cast<const void*>(&attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1>)}) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4W_LDS);
-        if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, F4W_LDS, hipGetErrorString(e)); return -2; }
-      }
-      configured = true;
-    }
+    for (const void* f : {reinterpret_cast<const void*>(&attn_fwd4w_kernel<1>), reinterpret_cast<const void*>(&attn_fwd4w_kernel<F4W_OCC2 ? 2 : 1>)})
+      if (int rc = crl_enable_lds(f, F4W_LDS, who)) return rc;
     const unsigned g4 = (unsigned)((Nq + 255) / 256) * B * H;
     const bool one_per_cu = g_fwd_mode == 3 || !F4W_OCC2;
     // persistent when there are more query blocks than workgroup slots: the resident workgroups pull blocks from the per-XCD ticket lists
@@ -1568,6 +1563,8 @@ static int bwd_chain_length(int nkt, int BH, bool stream, int* qsplit = nullptr)
   struct Memo { int nkt, bh, cu, c, split; };
   static Memo memo[8];
   static int memo_n = 0, memo_next = 0;
+  static std::mutex memo_mu;
+  std::lock_guard<std::mutex> memo_lock(memo_mu);
   const int ncu = crl_gemm_cus();
   for (int i = 0; i < memo_n; ++i)
     if (memo[i].nkt == nkt && memo[i].bh == BH && memo[i].cu == ncu) {
@@ -1715,15 +1712,9 @@ extern "C" int crl_attn_bwd(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (need && ws && ws_bytes >= need) {
     // ---- fused single pass: row constants, then dK / dV / partial dQ slabs from one recomputation, then the slab reduce
     CRL_CHECK(((uintptr_t)ws % 16) == 0 && (dq_rs % 8) == 0, "%s: workspace / dq must be 16-byte aligned", who);
-    static bool configured = false;
-    if (!configured) {
-      for (const void* f : {reinterpret_cast<const void*>(&attn_bwd_sp_kernel<false>), reinterpret_cast<const void*>(&attn_bwd_sp_kernel<true>),
-                            reinterpret_cast<const void*>(&attn_bwd_spx_kernel)}) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, f == reinterpret_cast<const void*>(&attn_bwd_spx_kernel) ? SPX_LDS : SP_LDS);
-        if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, SP_LDS, hipGetErrorString(e)); return -2; }
-      }
-      configured = true;
-    }
+    for (const void* f : {reinterpret_cast<const void*>(&attn_bwd_sp_kernel<false>), reinterpret_cast<const void*>(&attn_bwd_sp_kernel<true>),
+                          reinterpret_cast<const void*>(&attn_bwd_spx_kernel)})
+      if (int rc = crl_enable_lds(f, f == reinterpret_cast<const void*>(&attn_bwd_spx_kernel) ? SPX_LDS : SP_LDS, who)) return rc;
     a.fused_delta = 0;
     attn_delta_kernel<<<(unsigned)((rows * 8 + 255) / 256), 256, 0, s>>>(a);
     CRL_LAUNCH_CHECK("crl_attn_bwd(delta)");

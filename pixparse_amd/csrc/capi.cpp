@@ -14,6 +14,23 @@ extern "C" void crl_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crl_last_error(void) { return g_err; }
+
+// declared in common.h: a kernel's dynamic-LDS limit is a per-device attribute -- set once per (kernel, device), thread-safe
+#include <mutex>
+#include <utility>
+int crl_enable_lds(const void* kernel, int bytes, const char* who) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { crl_set_error("%s: no current device", who); return -2; }
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& d : done)
+    if (d.first == kernel && d.second == dev) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { crl_set_error("%s: cannot enable %d bytes of LDS: %s", who, bytes, hipGetErrorString(e)); return -2; }
+  done.emplace_back(kernel, dev);
+  return 0;
+}
 extern "C" int crl_version(void) { return 1; }
 
 // ---- live per-kernel timing (include/crl.h: crl_prof_begin / crl_prof_end) -------------------------------------------

@@ -14,6 +14,9 @@ typedef unsigned short u16;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 extern "C" void crl_set_error(const char* fmt, ...);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set once per (kernel, device), under a mutex (capi.cpp).
+// Returns 0, or -2 with the error text set.
+int crl_enable_lds(const void* kernel, int bytes, const char* who);
 
 #define CRL_CHECK(cond, ...)                 \
   do {                                       \

@@ -23,12 +23,7 @@ __global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, co
 extern "C" int crl_debug_occupy_cus(int n_cus, double max_seconds, const int* stop_flag, void* stream) {
   CRL_CHECK(n_cus >= 1 && n_cus <= 255, "crl_debug_occupy_cus: n_cus %d outside [1, 255]", n_cus);
   CRL_CHECK(max_seconds > 0.0 && max_seconds <= 120.0, "crl_debug_occupy_cus: max_seconds must be in (0, 120]");
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    if (e != hipSuccess) { crl_set_error("crl_debug_occupy_cus: cannot enable 160 KiB LDS: %s", hipGetErrorString(e)); return -2; }
-    configured = true;
-  }
+  if (int rc = crl_enable_lds(reinterpret_cast<const void*>(&occupy_kernel), 163840, "crl_debug_occupy_cus")) return rc;
   occupy_kernel<<<n_cus, 64, 163840, as_stream(stream)>>>((unsigned long long)(max_seconds * 1e8), stop_flag);
   CRL_LAUNCH_CHECK("crl_debug_occupy_cus");
   return 0;

@@ -223,7 +223,6 @@ int launch_epi(const GemmArgs& a, int epi, int bk, int nsplit, hipStream_t s) {
 int crl_gemm256_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
 int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s);
 bool crl_gemm4w_overlaps(int layout, int epi, const gemmc::GemmArgs& a, int nsplit);   // the 4-wave kernel would run this launch with the epilogue of tile T inside the main loop of tile T + 1
-int crl_gemm2x_launch(int layout, int epi, const gemmc::GemmArgs& a, hipStream_t s);
 
 // ---- launch geometry of the persistent kernels + the ticket-counter pool of the dynamic tile scheduler (gemm_common.h) ----
 #include <atomic>
@@ -281,7 +280,7 @@ extern "C" int crl_gemm_set_schedule(int dynamic) {
 #define G_SMALL_SPLIT_MIN_NK 6     // 32 = the round-2 rule (A/B)
 #endif
 struct Plan { bool big; int nsplit; int64_t chunk; };
-static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel, 3 force the 256x128 two-per-CU kernel (tests, A/B)
+static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force a 256x256 kernel (tests, A/B)
 // which 256x256 kernel serves the "big" launches: 0 = gemm256.hip (8 waves, two per SIMD), 1 = gemm4w.hip (4 waves, one per SIMD: round 5),
 // 2 = per launch (default).  Same-box table (profiles/r5_gemm4w_grouped.txt): the 4-wave main loop is 3-16 % faster wherever a workgroup walks
 // >= 32 K tiles behind a store-only epilogue (every weight gradient: +12-16 %, the K = 3072 / 4096 dgrads: +3-6 %, fc2 plain: +3 %), equal at
@@ -302,12 +301,6 @@ extern "C" int crl_gemm_set_big_kernel(int which) {
   g_big4w = which;
   return 0;
 }
-#ifndef G_AUTO_2X
-#define G_AUTO_2X 0      // (rounds 2-4: 1) auto policy: very wide NT outputs (the LM head: N = 50304) went to the 256x128 two-workgroups-per-CU kernel
-#endif                   // (gemm2x.hip): same-box A/B +8 % there, +15 % at 8192^3; the K = 1024 encoder shapes are faster on the
-                         // 256x256 kernel + wave-quantisation split (A/B table in DESIGN.md), so they stay there.  Round 5: with the grouped
-                         // tile order the 256x256 kernels run the LM head in 735 us against 830 (profiles/r5_gemm_wide.txt) and 8192^3 at
-                         // 1.46-1.50 PF/s against 1.24: the two-per-CU kernel stays selectable (policy 3) but is no longer chosen
 static Plan plan_gemm(int layout, int epilogue, int64_t M, int64_t N, int64_t K, bool allow_split) {
   Plan p{false, 1, 0};
   const int64_t nk = (K + 63) / 64;
@@ -353,40 +346,8 @@ static float g_round_a = 5.0f, g_round_b = 22.0f;
 static int g_calibrated = 0;
 extern "C" int crl_gemm_set_quant_cost(float c) { g_quant_cost = c; return 0; }
 static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap);
-// Round 5: the remainder launch runs BESIDE the persistent launch on a side stream of the library (fork / join by events around the two
-// launches; the remainder is enqueued first, so its few workgroups are placed before the persistent kernel takes every CU, and the resident
-// workgroups of the persistent kernel that start late simply pull fewer tiles: that is what the dynamic schedule is for).  The cut then
-// costs (almost) nothing, so every NT / NN launch whose last round of 256x256 tiles would be less than 60 % full is cut to whole rounds --
-// also at K = 1024, where the serial cut never paid: 776 tiles = 3.03 rounds used to cost 4.
-// MEASURED AND SWITCHED OFF (profiles/r5_gemm_async_xcd.txt): every K = 1024 encoder launch got SLOWER (qkv 286 -> 309 us, proj + residual
-// 160 -> 174, dgrad proj 121 -> 137): the two event edges between the streams cost more than the partial round they remove.  The code stays
-// behind crl_gemm_set_async_remainder(1); the default is the round-3 cost model with serial launches.
-#ifndef G_REM_ASYNC
-#define G_REM_ASYNC 0
-#endif
-static int g_rem_async = G_REM_ASYNC;
-extern "C" int crl_gemm_set_async_remainder(int on) { g_rem_async = on ? 1 : 0; return 0; }
-struct RemSide { hipStream_t stream; hipEvent_t ev[32]; unsigned next; bool ok; };
-static RemSide* rem_side() {
-  static RemSide rs;
-  static bool init = false;
-  if (!init) {
-    init = true;
-    rs.ok = hipStreamCreateWithFlags(&rs.stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 32 && rs.ok; ++i) rs.ok = hipEventCreateWithFlags(&rs.ev[i], hipEventDisableTiming) == hipSuccess;
-    rs.next = 0;
-  }
-  return &rs;
-}
 static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
   if (layout == CRL_TN || g_quant_cost < 0.f) return -1;      // (the cut is along the rows of a row-major A: never for the weight-gradient layout)
-  if (g_rem_async) {
-    const int64_t ntn_ = (N + 255) / 256, ncu_ = crl_gemm_cus(), tiles = ((M + 255) / 256) * ntn_;
-    const int64_t whole = tiles / ncu_, part = tiles - whole * ncu_;
-    if (whole < 1 || part == 0 || 10 * part >= 6 * ncu_) return -1;
-    const int64_t r = std::min((whole * ncu_) / ntn_, M / 256);
-    return (r >= 1 && M - 256 * r > 0) ? r : -1;
-  }
   const int64_t ntn = (N + 255) / 256, rmax = M / 256, ncu = crl_gemm_cus();
   const int64_t wmax = (((M + 255) / 256) * ntn + ncu - 1) / ncu;   // rounds of the uncut launch
   auto round_us = [](double k) { return (double)g_round_a + (double)g_round_b * k / 1024.0; }; // one round of 256x256 tiles (plain epilogue, sustained clock)
@@ -516,7 +477,7 @@ extern "C" int crl_gemm_calibrate(void* ws, size_t ws_bytes, void* stream) {
 }
 
 extern "C" int crl_gemm_set_policy(int policy) {
-  if (policy < 0 || policy > 3) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
+  if (policy < 0 || policy > 2) { crl_set_error("crl_gemm_set_policy: bad policy %d", policy); return -1; }
   g_policy = policy;
   return 0;
 }
@@ -528,7 +489,7 @@ extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t
     const int ns = few_tiles_split(layout, epilogue, M, N, K);
     if (ns > 1) return (size_t)ns * M * N * sizeof(float);
   }
-  if (p.big && g_policy != 3) {
+  if (p.big) {
     const int64_t r = quant_rows(layout, epilogue, M, N, K);
     if (r > 0) {
       const int ns = rem_split(epilogue, M - 256 * r, N, K, 8);
@@ -587,14 +548,6 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   if (bk == 32) { p.big = false; p.nsplit = 1; p.chunk = (K + 31) / 32; }
   a.kchunk = (int)p.chunk;
   a.slab_stride = 0;
-  {
-    // 256x128 tiles, two independent workgroups per CU: one's epilogue runs under the other's MFMA loop (gemm2x.hip)
-    const bool can2x = layout != CRL_TN && bk == 64 && p.nsplit == 1 && M >= 128 && N >= 64;
-    if (can2x && (g_policy == 3 || (g_policy == 0 && G_AUTO_2X && p.big && layout == CRL_NT && N >= 8192))) {
-      a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 127) / 128);
-      return crl_gemm2x_launch(layout, epilogue, a, s);
-    }
-  }
   if (p.big) { a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 255) / 256); }
   if (p.nsplit > 1) {
     GemmArgs b = a;
@@ -636,17 +589,6 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     rest.ntm = (int)((M - m1 + BM - 1) / BM); rest.ntn = (int)((N + BN - 1) / BN);
     rest.kchunk = (int)((K + 63) / 64);
     const int64_t rem = M - m1;
-    // fork: the remainder (disjoint output rows, its own scratch) goes to the side stream, ordered behind everything `s` holds so far
-    hipStream_t sr = s;
-    hipEvent_t e_join = nullptr;
-    RemSide* side = g_rem_async ? rem_side() : nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (side && side->ok && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-      hipEvent_t e_fork = side->ev[side->next++ & 31];
-      e_join = side->ev[side->next++ & 31];
-      if (hipEventRecord(e_fork, s) == hipSuccess && hipStreamWaitEvent(side->stream, e_fork, 0) == hipSuccess) sr = side->stream;
-      else e_join = nullptr;
-    }
     auto launch_rest = [&]() -> int {
       const int ns = rem_split(epilogue, rem, N, K, 8);
       if (ns > 1 && ws && ws_bytes >= (size_t)ns * rem * N * sizeof(float)) {
@@ -655,32 +597,33 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
         sl.C = ws; sl.ldc = (int)N; sl.slab_stride = (size_t)rem * N;
         sl.kchunk = (int)((K / 64 + ns - 1) / ns);
         const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
-        if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, sr) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, sr))) return rc;
+        if (int rc = (layout == CRL_NT ? launch_epi<CRL_NT>(sl, CRL_EPI_F32, 64, nsl, s) : launch_epi<CRL_NN>(sl, CRL_EPI_F32, 64, nsl, s))) return rc;
         const unsigned blocks = (unsigned)(((size_t)rem * N / 4 + 255) / 256);
         if (epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC)
-          splitk_reduce_kernel<<<blocks, 256, 0, sr>>>((const float*)ws, nsl, (size_t)rem * N, (float*)rest.C, (int)rem, (int)N, (int)ldc, epilogue == CRL_EPI_F32_ACC);
+          splitk_reduce_kernel<<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (float*)rest.C, (int)rem, (int)N, (int)ldc, epilogue == CRL_EPI_F32_ACC);
         else if (epilogue == CRL_EPI_BF16)
-          splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, sr>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
+          splitk_reduce_epi_kernel<CRL_EPI_BF16><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, nullptr, 0, a.colscale, a.colscale_cols);
         else
-          splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, sr>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, rest.resid, (int)ldr);
+          splitk_reduce_epi_kernel<CRL_EPI_F32_RESID><<<blocks, 256, 0, s>>>((const float*)ws, nsl, (size_t)rem * N, (int)rem, (int)N, rest.bias, rest.C, (int)ldc, rest.resid, (int)ldr);
         CRL_LAUNCH_CHECK("crl_gemm_bf16(remainder reduce)");
         return 0;
       }
       switch (layout) {
-        case CRL_NT: return launch_epi<CRL_NT>(rest, epilogue, 64, 1, sr);
-        default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, sr);
+        case CRL_NT: return launch_epi<CRL_NT>(rest, epilogue, 64, 1, s);
+        default: return launch_epi<CRL_NN>(rest, epilogue, 64, 1, s);
       }
     };
+    // G_REM_FIRST (default): the remainder launch (+ its reduce) is enqueued first -- its few workgroups start while the chip still drains the
+    // previous kernel and the persistent launch ends the call at full width; 0 = the round-3 order (A/B: profiles/r6_gemm_rem_order.txt)
 #ifndef G_REM_FIRST
 #define G_REM_FIRST 1
 #endif
-    int rc = 0;
-    if (!G_REM_FIRST && !e_join) rc = big_launch(layout, epilogue, big, 1, s);
-    if (!rc) rc = launch_rest();                  // (async form) enqueued FIRST: its workgroups are placed before the persistent kernel takes every CU
-    if (e_join && hipEventRecord(e_join, sr) != hipSuccess) { crl_set_error("crl_gemm_bf16: cannot record the join event"); rc = rc ? rc : -2; }
-    if (!rc && (G_REM_FIRST || e_join)) rc = big_launch(layout, epilogue, big, 1, s);
-    if (e_join && hipStreamWaitEvent(s, e_join, 0) != hipSuccess) { crl_set_error("crl_gemm_bf16: cannot join the side stream"); rc = rc ? rc : -2; }
-    return rc;
+    if (G_REM_FIRST) {
+      if (int rc = launch_rest()) return rc;
+      return big_launch(layout, epilogue, big, 1, s);
+    }
+    if (int rc = big_launch(layout, epilogue, big, 1, s)) return rc;
+    return launch_rest();
   }
   if (g_policy == 0 && bk == 64) {
     const int ns = few_tiles_split(layout, epilogue, M, N, K);

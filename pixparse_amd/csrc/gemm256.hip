@@ -291,13 +291,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const GemmArgs g) {
 
 template <int LAYOUT, int EPI>
 int launch256_one(const GemmArgs& a, int nsplit, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<LAYOUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (e != hipSuccess) { crl_set_error("gemm256: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -2; }
-    configured = true;
-  }
+  if (int rc = crl_enable_lds(reinterpret_cast<const void*>(&gemm256_kernel<LAYOUT, EPI>), 131072, "crl_gemm_bf16(256x256)")) return rc;
   int grid_x = a.ntm * a.ntn;
   GemmArgs b = a;
   b.sched = nullptr;

@@ -330,16 +330,14 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
 // sits in an epilogue with its matrix pipes idle and the tile-sized store traffic of the 256 CUs no longer arrives in one burst.  The last
 // tile of a workgroup is finished by a drain statement.  Same arithmetic as epilogue4w / gemm_epilogue.h (bit-identical results); the
 // accumulators are carried from statement to statement as in-out physical-register operands (the compiler leaves them in place).
-// RESID = true: the fp32-residual form (CRL_EPI_F32_RESID, NT): C = resid + round_bf(acc + bias).  The rounded term is exactly representable in
-// bf16, so the same 128 packed registers carry it; the 64 residual pieces of 16 bytes per lane are requested nine MFMAs apart, six in flight, and
-// each is unpacked / added / stored 48 MFMAs behind its request.
-template <int LAYOUT, bool RESID>
+// (An fp32-residual variant of this form was built in round 5 and measured slower than the 8-wave kernel: profiles/r5_gemm4w_ovl_resid.txt,
+// removed in round 6, diff in profiles/r6_experiments/.)
+template <int LAYOUT>
 __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool B_TR = (LAYOUT != CRL_NT);
   static_assert(LAYOUT != CRL_TN, "weight gradients have fp32 outputs: classic form");
-  static_assert(!RESID || LAYOUT == CRL_NT, "the residual form exists for the forward layout");
-  constexpr uint32_t ES = RESID ? 4u : 2u;
+  constexpr uint32_t ES = 2u;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -384,10 +382,7 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
   const uint32_t nrecC = (uint32_t)(((size_t)(g.M - 1) * (uint32_t)g.ldc + (uint32_t)g.N) * ES);
   const u32x4 rc_live = make_srd(g.C, nrecC), rc_dead = make_srd(g.C, 0);       // no previous tile: every store falls off a descriptor without records
   const u32x4 srdBias = make_srd(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
-  const uint32_t s_cstep = 16u * (uint32_t)g.ldc * ES, s_cscols = RESID ? 0u : (uint32_t)g.colscale_cols, s_cscale = __float_as_uint(RESID ? 1.f : g.colscale);
-  const uint32_t nrecR = RESID ? (uint32_t)(((size_t)(g.M - 1) * (uint32_t)g.ldr + (uint32_t)g.N) * 4u) : 0u;
-  const u32x4 rr_live = make_srd(g.resid, nrecR);
-  const uint32_t s_rstep = 16u * (uint32_t)g.ldr * 4u;
+  const uint32_t s_cstep = 16u * (uint32_t)g.ldc * ES, s_cscols = (uint32_t)g.colscale_cols, s_cscale = __float_as_uint(g.colscale);
 
   f32x4 c[8][8];
 #pragma unroll
@@ -411,21 +406,14 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
     const int tsw = tr_swz(8 * tg + tq);
     auto tr_addr = [&](int j) { return (uint32_t)((8 * tg + tq) * 256 + ((((2 * j) ^ tsw) + (tp >> 1)) << 4) + 8 * (tp & 1)); };
     // the previous tile's epilogue: lane (li, lq) stores row 128 wr + 16 i + li, the 8 columns 128 wc + 32 pr + 8 bitswap(lq) .. of every strip pair
-    //   (fp32 form: lane (li, lq) owns the 4 columns 16 j + 4 lq .. of every 16-column strip)
-    const uint32_t voffC = RESID ? (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 4u + (uint32_t)(128 * wc + 4 * lq) * 4u
-                                 : (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
-    const uint32_t voffR = (uint32_t)(128 * wr + li) * (uint32_t)g.ldr * 4u + (uint32_t)(128 * wc + 4 * lq) * 4u;
+    const uint32_t voffC = (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
     const uint32_t colv = (uint32_t)(pn0 + 128 * wc + 4 * lq), voffBias = colv * 4u;
-    const u32x4 srdC = have_prev ? rc_live : rc_dead, srdR = rr_live;
+    const u32x4 srdC = have_prev ? rc_live : rc_dead;
     uint32_t s_crow = ((uint32_t)pm0 * (uint32_t)g.ldc + (uint32_t)pn0) * ES;
-    uint32_t s_rrow = ((uint32_t)pm0 * (uint32_t)g.ldr + (uint32_t)pn0) * 4u;
     u32x4 srdA = ra, srdB = rb;
     uint32_t s_offA = ((uint32_t)m0 * g.lda) * 2u, s_offB = B_TR ? (uint32_t)n0 * 2u : ((uint32_t)n0 * g.ldb) * 2u;
     uint32_t s_live = (uint32_t)nk, s_cnt = (uint32_t)nk, s_t;
-    if constexpr (RESID) {
-      uint32_t arAk0 = unitA + km_k0, arAk1 = unitA + km_k1, arBk0 = unitB + km_k0, arBk1 = unitB + km_k1;
-#include "gemm4w_body_nt_ovlr.inc"
-    } else if constexpr (LAYOUT == CRL_NT) {
+    if constexpr (LAYOUT == CRL_NT) {
       uint32_t arAk0 = unitA + km_k0, arAk1 = unitA + km_k1, arBk0 = unitB + km_k0, arBk1 = unitB + km_k1;
 #include "gemm4w_body_nt_ovl.inc"
     } else {
@@ -451,18 +439,11 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
     int t2 = threadIdx.x;
     asm volatile("" : "+v"(t2));
     const int lane = t2 & 63, li = lane & 15, lq = lane >> 4;
-    const uint32_t voffC = RESID ? (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 4u + (uint32_t)(128 * wc + 4 * lq) * 4u
-                                 : (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
-    const uint32_t voffR = (uint32_t)(128 * wr + li) * (uint32_t)g.ldr * 4u + (uint32_t)(128 * wc + 4 * lq) * 4u;
+    const uint32_t voffC = (uint32_t)(128 * wr + li) * (uint32_t)g.ldc * 2u + (uint32_t)(128 * wc + 8 * (((lq & 1) << 1) | (lq >> 1))) * 2u;
     const uint32_t colv = (uint32_t)(pn0 + 128 * wc + 4 * lq), voffBias = colv * 4u;
-    const u32x4 srdC = rc_live, srdR = rr_live;
+    const u32x4 srdC = rc_live;
     uint32_t s_crow = ((uint32_t)pm0 * (uint32_t)g.ldc + (uint32_t)pn0) * ES;
-    uint32_t s_rrow = ((uint32_t)pm0 * (uint32_t)g.ldr + (uint32_t)pn0) * 4u;
-    if constexpr (RESID) {
-#include "gemm4w_drain_ovlr.inc"
-    } else {
 #include "gemm4w_drain_ovl.inc"
-    }
   }
   if (dyn && tid == 0) sched_leave(g.sched, gridDim.x);
 }
@@ -470,9 +451,7 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_ovl_kernel(const GemmArgs g) {
 // the overlapped form needs whole column tiles (its stores are not column-masked), a contraction long enough to hold the 32 stores of the
 // previous tile (five peeled K tiles) and the plain bf16 epilogue
 #ifndef G4_OVERLAP
-#define G4_OVERLAP 1      // bit 0: the plain bf16 epilogue; bit 1: the fp32-residual epilogue -- measured and left OFF (profiles/r5_gemm4w_ovl_resid.txt:
-                          // proj + residual 193.6 us against 162.0 for the 8-wave kernel: the launch moves 8 bytes per output element through HBM, and six
-                          // 1-KiB residual pieces in flight per wave do not cover the loaded latency; there are no registers for a deeper queue)
+#define G4_OVERLAP 1
 #endif
 static int g4_overlap = G4_OVERLAP;
 bool crl_gemm4w_can_overlap(int layout, int epi, const GemmArgs& a, int nsplit) {
@@ -480,19 +459,12 @@ bool crl_gemm4w_can_overlap(int layout, int epi, const GemmArgs& a, int nsplit) 
   // a workgroup with one or two tiles pays the entry + drain statements for nothing (cfg-2, M = 19 208: 27.3 ms per step overlapped against
   // 27.05 classic, profiles/r5_cfg2_ab.txt): the overlapped form from three rounds of tiles on
   if ((int64_t)a.ntm * a.ntn < 3 * (int64_t)crl_gemm_cus() && g4_overlap != 7) return false;
-  if (epi == CRL_EPI_BF16) return layout != CRL_TN && (a.ldc % 8) == 0;
-  if (epi == CRL_EPI_F32_RESID) return (g4_overlap & 2) && layout == CRL_NT && (a.ldc % 4) == 0 && (a.ldr % 4) == 0 && a.resid != nullptr;
-  return false;
+  return epi == CRL_EPI_BF16 && layout != CRL_TN && (a.ldc % 8) == 0;
 }
 
-template <int LAYOUT, bool RESID>
+template <int LAYOUT>
 int launch4w_ovl(const GemmArgs& a, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_ovl_kernel<LAYOUT, RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    if (e != hipSuccess) { crl_set_error("gemm4w: cannot enable 160 KiB LDS: %s", hipGetErrorString(e)); return -2; }
-    configured = true;
-  }
+  if (int rc = crl_enable_lds(reinterpret_cast<const void*>(&gemm4w_ovl_kernel<LAYOUT>), 163840, "crl_gemm_bf16(4w, overlapped epilogue)")) return rc;
   int grid_x = a.ntm * a.ntn;
   GemmArgs b = a;
   b.sched = nullptr;
@@ -501,19 +473,14 @@ int launch4w_ovl(const GemmArgs& a, hipStream_t s) {
     grid_x = ncu;
     if (crl_gemm_dynamic()) { bool ok; b.sched = crl_sched_slot(s, &ok); if (!ok) return -2; }
   }
-  gemm4w_ovl_kernel<LAYOUT, RESID><<<dim3(grid_x, 1), T4W, 163840, s>>>(b);
+  gemm4w_ovl_kernel<LAYOUT><<<dim3(grid_x, 1), T4W, 163840, s>>>(b);
   CRL_LAUNCH_CHECK("crl_gemm_bf16(4w, overlapped epilogue)");
   return 0;
 }
 
 template <int LAYOUT, int EPI>
 int launch4w_one(const GemmArgs& a, int nsplit, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<LAYOUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    if (e != hipSuccess) { crl_set_error("gemm4w: cannot enable 160 KiB LDS: %s", hipGetErrorString(e)); return -2; }
-    configured = true;
-  }
+  if (int rc = crl_enable_lds(reinterpret_cast<const void*>(&gemm4w_kernel<LAYOUT, EPI>), 163840, "crl_gemm_bf16(4w)")) return rc;
   int grid_x = a.ntm * a.ntn;
   GemmArgs b = a;
   b.sched = nullptr;
@@ -544,12 +511,11 @@ int launch4w_epi(const GemmArgs& a, int epi, int nsplit, hipStream_t s) {
 }  // namespace
 
 // called by crl_gemm_bf16 (gemm.hip): same contract as crl_gemm256_launch
-extern "C" int crl_gemm_set_overlap(int on) { g4_overlap = on & 7; return 0; }    // 0 off; bit 0 the plain bf16 epilogue, bit 1 the fp32-residual epilogue; 7 = both, also for launches of fewer than three rounds of tiles (tests)
+extern "C" int crl_gemm_set_overlap(int on) { g4_overlap = on & 7; return 0; }    // 0 off; 1 on (default); 7 = also for launches of fewer than three rounds of tiles (tests)
 bool crl_gemm4w_overlaps(int layout, int epi, const gemmc::GemmArgs& a, int nsplit) { return crl_gemm4w_can_overlap(layout, epi, a, nsplit); }
 int crl_gemm4w_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
   if (crl_gemm4w_can_overlap(layout, epi, a, nsplit)) {
-    if (epi == CRL_EPI_F32_RESID) return launch4w_ovl<CRL_NT, true>(a, s);
-    return layout == CRL_NT ? launch4w_ovl<CRL_NT, false>(a, s) : launch4w_ovl<CRL_NN, false>(a, s);
+    return layout == CRL_NT ? launch4w_ovl<CRL_NT>(a, s) : launch4w_ovl<CRL_NN>(a, s);
   }
   switch (layout) {
     case CRL_NT: return launch4w_epi<CRL_NT>(a, epi, nsplit, s);

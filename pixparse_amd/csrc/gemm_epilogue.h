@@ -1,4 +1,4 @@
-// Epilogue of the 256-row MFMA GEMM kernels (gemm256.hip: 256x256 tile, 8 waves; gemm2x.hip: 256x128 tile, 4 waves).
+// Epilogue of the 256-row MFMA GEMM kernels (gemm256.hip: 256x256 tile, 8 waves; gemm4w.hip takes the arithmetic helpers).
 // Both leave the same per-wave accumulator block: acc[qm][qn][i][j] = 16x16 tile at rows 128 qm + 64 wr + 16 i and columns
 // QN qn + 32 wc + 16 j of the workgroup tile (QN = 128 / 64), lane (li = lane & 15, lq = lane >> 4) holding C[row li][col 4 lq + 0..3].
 #pragma once

@@ -100,12 +100,6 @@ class Gen:
         # overlapped epilogue: the previous output tile's results, packed to bf16 -- tile (i, j) = 2 registers at P + 2 (8 i + j)
         self.P = (r + 3) & ~3
         self.n_hand = self.P + 128 if ovl else r
-        # fp32-residual form ('resid'): RQ loaded residual pieces (4 registers each) in flight + two sets of 4 unpack / result registers
-        self.RQ = 6
-        if ovl == 'resid':
-            self.L = self.n_hand
-            self.T = self.L + 4 * self.RQ
-            self.n_hand = self.T + 8
 
     def addr(self, name, slot):
         """(register text, immediate part) of ring slot `slot` for base operand `name`"""
@@ -133,7 +127,7 @@ class Gen:
                 I(f'ds_read_b64_tr_b16 v[{base + 2}:{base + 3}], {reg} offset:{off + 1024}', 'ds', writes=vregs(base + 2, 2), tag=tag)]
 
     def vops(self):
-        return self.bases + ['voffA', 'voffB'] + (['voffBias', 'voffC', 'colv'] if self.ovl else []) + (['voffR'] if self.ovl == 'resid' else [])
+        return self.bases + ['voffA', 'voffB'] + (['voffBias', 'voffC', 'colv'] if self.ovl else [])
 
     # ---- overlapped epilogue of the PREVIOUS output tile (plain bf16: bias, column scale, bf16 rounding; gemm_epilogue.h operation for operation)
     def readout(self):
@@ -163,28 +157,6 @@ class Gen:
                         I(f'v_pk_mul_f32 v[{t + 2}:{t + 3}], v[{t + 2}:{t + 3}], v[{32 + 2 * j}:{33 + 2 * j}] op_sel_hi:[1,0]', 'valu'),
                         I(f'v_cvt_pk_bf16_f32 v{self.P + 2 * n}, v{t}, v{t + 1}', 'valu'),
                         I(f'v_cvt_pk_bf16_f32 v{self.P + 2 * n + 1}, v{t + 2}, v{t + 3}', 'valu')]
-        return out
-
-    # ---- fp32-residual form: C = resid + round_bf(acc + bias); the rounded term is what the read-out packed into P (exactly representable)
-    def resid_load(self, u):
-        """16 bytes of the residual tile for accumulator tile (i, j) = (u >> 3, u & 7): row 16 i + li, columns 16 j + 4 lq .. + 3"""
-        q = self.L + 4 * (u % self.RQ)
-        out = [I(f'buffer_load_dwordx4 v[{q}:{q + 3}], {op("voffR")}, {op("srdR")}, {op("s_rrow")} offen offset:{64 * (u & 7)}', 'vmem', tag=('ld', u))]
-        if (u & 7) == 7:
-            out.append(I(f's_add_u32 {op("s_rrow")}, {op("s_rrow")}, {op("s_rstep")}', 'salu'))
-        return out
-
-    def resid_finish(self, u):
-        q = self.L + 4 * (u % self.RQ)
-        t = self.T + 4 * (u & 1)
-        p0 = self.P + 2 * u
-        out = [I('VMWAIT', 'vmwait', tag=('ld', u)),
-               I(f'v_lshlrev_b32 v{t}, 16, v{p0}', 'valu'), I(f'v_and_b32 v{t + 1}, 0xffff0000, v{p0}', 'valu'),
-               I(f'v_lshlrev_b32 v{t + 2}, 16, v{p0 + 1}', 'valu'), I(f'v_and_b32 v{t + 3}, 0xffff0000, v{p0 + 1}', 'valu')]
-        out += [I(f'v_add_f32 v{t + r}, v{q + r}, v{t + r}', 'valu') for r in range(4)]
-        out.append(I(f'buffer_store_dwordx4 v[{t}:{t + 3}], {op("voffC")}, {op("srdC")}, {op("s_crow")} offen offset:{64 * (u & 7)}', 'vmem', tag='store'))
-        if (u & 7) == 7:
-            out.append(I(f's_add_u32 {op("s_crow")}, {op("s_crow")}, {op("s_cstep")}', 'salu'))
         return out
 
     def store_unit(self, u):
@@ -381,15 +353,8 @@ def generate(layout, ovl=None):
 
         def put(g, inss):
             fill.setdefault(g // 128, {}).setdefault(((g % 128) // 64, g % 64), []).extend(inss)
-        if ovl == 'resid':
-            # 64 accumulator tiles: the residual piece of tile u is requested at gap 6 + 9 u and consumed (unpack, add, store) 48 gaps later --
-            # RQ = 6 pieces in flight, ~800 cycles of lead; a piece that is late stalls the wave at its counted wait, nothing else
-            for u in range(64):
-                put(6 + 9 * u, G.resid_load(u))
-                put(6 + 9 * u + 48 + 4, G.resid_finish(u))
-        else:
-            for u in range(32):
-                put(24 + 18 * u, G.store_unit(u))
+        for u in range(32):
+            put(24 + 18 * u, G.store_unit(u))
         for t in range(5):
             emit_tile(t, t, t == 0, fill.get(t))
         first_loop = 5
@@ -421,20 +386,9 @@ def generate_drain(ovl='bf16'):
     H.drain('s_waitcnt vmcnt(0)')
     for ins in G.readout_math():
         H.emit(ins)
-    if ovl == 'resid':
-        for u in range(G.RQ):
-            for ins in G.resid_load(u):
-                H.emit(ins)
-        for u in range(64):
-            for ins in G.resid_finish(u):
-                H.emit(ins)
-            if u + G.RQ < 64:
-                for ins in G.resid_load(u + G.RQ):
-                    H.emit(ins)
-    else:
-        for u in range(32):
-            for ins in G.store_unit(u):
-                H.emit(ins)
+    for u in range(32):
+        for ins in G.store_unit(u):
+            H.emit(ins)
     H.drain('s_waitcnt vmcnt(0)')
     return H.out, G
 
@@ -449,10 +403,10 @@ def render(stream, G):
     for ins in stream:
         lines += ins.text.split('\n\t')
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
-    srw = ['s_offA', 's_offB', 's_live', 's_cnt'] + (['s_crow'] if G.ovl else []) + (['s_rrow'] if G.ovl == 'resid' else [])
+    srw = ['s_offA', 's_offB', 's_live', 's_cnt'] + (['s_crow'] if G.ovl else [])
     outs = (ACC_IO if G.ovl else ACC_OUT) + ',\n      ' + f'"+{{s[{SRD["A"]}:{SRD["A"] + 3}]}}"(srdA), "+{{s[{SRD["B"]}:{SRD["B"] + 3}]}}"(srdB),\n      ' + \
         ', '.join(f'[{n}] "+&s"({n})' for n in srw) + ', [s_t] "=&s"(s_t)'
-    sin = ['s_ldsw', 's_itA', 's_halfA', 's_ktA', 's_itB', 's_halfB', 's_ktB'] + (['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'] if G.ovl else []) + (['srdR', 's_rstep'] if G.ovl == 'resid' else [])
+    sin = ['s_ldsw', 's_itA', 's_halfA', 's_ktA', 's_itB', 's_halfB', 's_ktB'] + (['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'] if G.ovl else [])
     ins_ = ', '.join(f'[{n}] "v"({n})' for n in G.vops()) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in sin)
     clob = ', '.join(f'"v{i}"' for i in range(G.n_hand)) + ', "vcc", "scc", "memory"'
     return (f'// GENERATED by gen_gemm4w.py ({G.layout}{", overlapped " + str(G.ovl) + " epilogue" if G.ovl else ""}) -- do not edit; see that file for the register map and the schedule\n'
@@ -464,16 +418,15 @@ def render_drain(stream, G):
     for ins in stream:
         lines += ins.text.split('\n\t')
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
-    outs = ACC_IO + ',\n      [s_crow] "+&s"(s_crow)' + (', [s_rrow] "+&s"(s_rrow)' if G.ovl == 'resid' else '')
-    ins_ = ', '.join(f'[{n}] "v"({n})' for n in ['voffBias', 'voffC', 'colv'] + (['voffR'] if G.ovl == 'resid' else [])) + ',\n      ' + \
-        ', '.join(f'[{n}] "s"({n})' for n in ['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'] + (['srdR', 's_rstep'] if G.ovl == 'resid' else []))
+    outs = ACC_IO + ',\n      [s_crow] "+&s"(s_crow)'
+    ins_ = ', '.join(f'[{n}] "v"({n})' for n in ['voffBias', 'voffC', 'colv']) + ',\n      ' + \
+        ', '.join(f'[{n}] "s"({n})' for n in ['srdBias', 'srdC', 's_cstep', 's_cscols', 's_cscale'])
     clob = ', '.join(f'"v{i}"' for i in range(G.n_hand)) + ', "vcc", "scc", "memory"'
     return ('// GENERATED by gen_gemm4w.py (epilogue of the last output tile, overlapped form) -- do not edit\n'
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
 
 
-FILES = [(f'gemm4w_body_{l}.inc', l, False) for l in KINDS] + [(f'gemm4w_body_{l}_ovl.inc', l, 'bf16') for l in ('nt', 'nn')] + \
-    [('gemm4w_body_nt_ovlr.inc', 'nt', 'resid')]
+FILES = [(f'gemm4w_body_{l}.inc', l, False) for l in KINDS] + [(f'gemm4w_body_{l}_ovl.inc', l, 'bf16') for l in ('nt', 'nn')]
 
 
 def generate_all(outdir):
@@ -482,7 +435,7 @@ def generate_all(outdir):
         with open(os.path.join(outdir, name), 'w') as f:
             f.write(render(stream, G))
         yield name, stream
-    for name, kind in (('gemm4w_drain_ovl.inc', 'bf16'), ('gemm4w_drain_ovlr.inc', 'resid')):
+    for name, kind in (('gemm4w_drain_ovl.inc', 'bf16'),):
         stream, G = generate_drain(kind)
         with open(os.path.join(outdir, name), 'w') as f:
             f.write(render_drain(stream, G))

@@ -320,12 +320,7 @@ int swin_launch(const char* who, SwinArgs& a, hipStream_t s) {
   constexpr int NW = waves_per_wg<BWD>();
   a.nWx = a.Wf / a.w; a.nWy = a.Hf / a.w; a.nwin = a.B * a.nWy * a.nWx;
   const size_t lds = swin_lds_bytes(BWD, a.w);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<BWD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    CRL_CHECK(e == hipSuccess, "%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e));
-    configured = true;
-  }
+  if (int rc = crl_enable_lds(reinterpret_cast<const void*>(&swin_attn_kernel<BWD, NW>), 160 * 1024, who)) return rc;
   const unsigned grid = (unsigned)(((a.nwin + NW - 1) / NW) * a.heads);
   swin_attn_kernel<BWD, NW><<<grid, 64 * NW, lds, s>>>(a);
   CRL_LAUNCH_CHECK(who);

@@ -26,7 +26,6 @@ SIGNATURES = {
     'crl_gemm_set_policy': (I, [I]),
     'crl_gemm_set_big_kernel': (I, [I]),
     'crl_gemm_set_overlap': (I, [I]),
-    'crl_gemm_set_async_remainder': (I, [I]),
     'crl_gemm_set_quant_cost': (I, [F]),
     'crl_gemm_calibrate_ws_bytes': (Z, []),
     'crl_gemm_calibrate': (I, [P, Z, P]),

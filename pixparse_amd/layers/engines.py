@@ -90,35 +90,6 @@ class _Base:
                           self.G(name + '.weight'), self.G(name + '.bias'), True,
                           dx_colsum=self.G(bias_of + '.bias') if bias_of else None)
 
-    # ---- an HBM-bound kernel beside a weight-gradient GEMM (PIXPARSE_AMD_TAIL_OVERLAP=n, default 0 = off): `side_fn` (a
-    # LayerNorm backward: reads / writes a few [M, D] tensors, no matrix work) goes to a side stream, `main_fn` (lin_wgrad of an independent
-    # Linear: power-bound split-K GEMM) is planned for 256 - n CUs (crl_gemm_set_reserved_cus), so that the side kernel's workgroups find free
-    # CUs; fork / join by events.  Same kernels, same arguments, same order of operations inside each stream: results are bit-identical.
-    _tail = None
-
-    def beside(self, side_fn, main_fn):
-        import os
-        n = int(os.environ.get('PIXPARSE_AMD_TAIL_OVERLAP', '0'))
-        if n <= 0 or torch.cuda.is_current_stream_capturing():
-            main_fn()
-            side_fn()
-            return
-        if _Base._tail is None:
-            _Base._tail = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
-        side, e0, e1 = _Base._tail
-        main = torch.cuda.current_stream()
-        e0.record(main)
-        side.wait_event(e0)
-        with torch.cuda.stream(side):       # enqueued first: its workgroups are placed before the GEMM's
-            side_fn()
-            e1.record(side)
-        ops.gemm_set_reserved_cus(n)
-        try:
-            main_fn()
-        finally:
-            ops.gemm_set_reserved_cus(0)
-        main.wait_event(e1)
-
     # Linear backward: wgrad + bias grad (dgrad is issued by the caller: its epilogue differs)
     def lin_wgrad(self, name, dy, x, has_bias=True, n=None, k=None):
         gw = self.G(name + '.weight')
@@ -249,8 +220,8 @@ class ViTEngine(_Base):
             ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
             self.lin_wgrad(bp + 'mlp.fc2', gb, act, has_bias=False)
             ops.linear_dgrad(dpre, self.W(bp + 'mlp.fc1.weight'), dh)
-            self.beside(lambda: self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb, bias_of=bp + 'attn.proj'),     # dx := dx2, gb := bf16(dx2)
-                        lambda: self.lin_wgrad(bp + 'mlp.fc1', dpre, h2))
+            self.lin_wgrad(bp + 'mlp.fc1', dpre, h2)
+            self.ln_bwd(bp + 'norm2', k + '.ln2', x2, None, dh, dx, True, gb, bias_of=bp + 'attn.proj')     # dx := dx2, gb := bf16(dx2)
             # ---- attention: x2 = xin + proj(attn(qkv(LN1(xin))))
             ops.linear_dgrad(gb, self.W(bp + 'attn.proj.weight'), do)
             self.lin_wgrad(bp + 'attn.proj', gb, o, has_bias=False)
@@ -258,9 +229,9 @@ class ViTEngine(_Base):
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o.view(B, N, D), do.view(B, N, D), lse, delta,
                          dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], self.heads, scale, False, q_prescaled=True)
             ops.linear_dgrad(dqkv, self.W(bp + 'attn.qkv.weight'), dh)
-            self.beside(lambda: self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb,    # dx := d(xin) = d(x3 of block i-1)
-                                            bias_of=f'blocks.{i - 1}.mlp.fc2' if i > 0 else None),
-                        lambda: self.lin_wgrad(bp + 'attn.qkv', dqkv, h1))
+            self.lin_wgrad(bp + 'attn.qkv', dqkv, h1)
+            self.ln_bwd(bp + 'norm1', k + '.ln1', xin, None, dh, dx, True, gb,    # dx := d(xin) = d(x3 of block i-1)
+                        bias_of=f'blocks.{i - 1}.mlp.fc2' if i > 0 else None)
             if on_layer_done:
                 on_layer_done(self.prefix + bp + 'norm1.weight')
         if a['pre_norm']:

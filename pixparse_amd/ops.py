@@ -49,14 +49,13 @@ _gemm_env_applied = False
 
 def _gemm_env():
     """A/B switches of the GEMM dispatch, read once: PIXPARSE_AMD_GEMM_BIG=0|1|2 (crl_gemm_set_big_kernel: 8-wave / 4-wave / per launch),
-    PIXPARSE_AMD_GEMM_OVERLAP=0|1 (crl_gemm_set_overlap), PIXPARSE_AMD_GEMM_ASYNC_REM=0|1 (crl_gemm_set_async_remainder)"""
+    PIXPARSE_AMD_GEMM_OVERLAP=0|1 (crl_gemm_set_overlap)"""
     global _gemm_env_applied
     if _gemm_env_applied:
         return
     _gemm_env_applied = True
     import os
-    for env, fn in (('PIXPARSE_AMD_GEMM_BIG', 'crl_gemm_set_big_kernel'), ('PIXPARSE_AMD_GEMM_OVERLAP', 'crl_gemm_set_overlap'),
-                    ('PIXPARSE_AMD_GEMM_ASYNC_REM', 'crl_gemm_set_async_remainder')):
+    for env, fn in (('PIXPARSE_AMD_GEMM_BIG', 'crl_gemm_set_big_kernel'), ('PIXPARSE_AMD_GEMM_OVERLAP', 'crl_gemm_set_overlap')):
         if os.environ.get(env):
             hip.call(fn, int(os.environ[env]))
 

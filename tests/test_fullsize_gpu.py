@@ -77,11 +77,109 @@ def test_attention_full_sequence_sampled_rows_and_identities(dev):
     assert float((a - b).abs().max()) < 2e-2 * float(b.abs().max()) + 0.5, float((a - b).abs().max())
 
 
-@pytest.mark.parametrize('policy', [0, 2, 3])
+def _attn_prod_check(dev, B, H, Nq, Nk, pairs, seed, label):
+    """the two hand-placed attention streams in the launch geometry the step uses, against fp32 recomputation of sampled rows / keys of
+    sampled (batch, head) pairs.  q is PRESCALED (bf16(raw * scale * log2 e), what the q | k | v projection's colscale epilogue writes):
+    forward = attn_fwd4w_kernel<2> (persistent, ticket-pulling), backward = attn_bwd_spx_kernel (automatic chain, query split of the
+    remainder chains, persistent) + slab reduce.  dq is the gradient of the UNscaled projection output (dS K scale)."""
+    from pixparse_amd import ops
+    d, scale = 64, 0.125
+    D = H * d
+    c = scale * ops.LOG2E
+    g = torch.Generator(device=dev).manual_seed(seed)
+    qkv = torch.empty(B, max(Nq, Nk), 3 * D, dtype=BF16, device=dev)
+    qkv.normal_(generator=g)
+    qkv[:, :, :D] *= c                                       # (bf16 in place: one rounding of the scaled value, like the epilogue's)
+    q, k, v = qkv[:, :Nq, :D], qkv[:, :Nk, D:2 * D], qkv[:, :Nk, 2 * D:]
+    d_o = torch.empty(B, Nq, D, dtype=BF16, device=dev).normal_(generator=g)
+    o = torch.full((B, Nq, D), float('nan'), dtype=BF16, device=dev)
+    lse = torch.full((B, H, Nq), float('nan'), device=dev)
+    ops.attn_fwd(q, k, v, o, lse, H, scale, False, q_prescaled=True)
+    dqkv = torch.full((B, max(Nq, Nk), 3 * D), float('nan'), dtype=BF16, device=dev)
+    dq, dk, dv = dqkv[:, :Nq, :D], dqkv[:, :Nk, D:2 * D], dqkv[:, :Nk, 2 * D:]
+    delta = torch.empty(2, B, H, Nq, device=dev)
+    ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, H, scale, False, q_prescaled=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all(), label
+    assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all(), label
+    LN2 = math.log(2.0)
+    pick = lambda n, m, must, sd: torch.unique(torch.cat([torch.randperm(n, generator=torch.Generator().manual_seed(sd))[:m],
+                                                           torch.tensor([x for x in must if 0 <= x < n])])).to(dev)
+    # the last (ragged: 45 live rows at 6189) query block, block boundaries; the remainder key block 6144..6188, chain boundaries (1024, 2048, ...)
+    rows = pick(Nq, 84, [0, 255, 256, Nq - 1, Nq - 2, (Nq - 1) // 256 * 256, (Nq - 1) // 256 * 256 + 7, 1023, 1024, 4095, 4096, 6143], seed)
+    keys = pick(Nk, 52, [0, 255, 256, Nk - 1, Nk - 20, (Nk - 1) // 256 * 256, (Nk - 1) // 256 * 256 + 9, 1023, 1024, 4095, 4096, 6143], seed + 1)
+    for (b, h) in pairs:
+        sl = slice(h * d, (h + 1) * d)
+        Q, K, V, O, dO = (t[b, :, sl].float() for t in (q, k, v, o, d_o))
+        z = Q[rows] @ K.t() * LN2                                               # natural-log logits of the sampled rows
+        P = torch.softmax(z, -1)
+        _close(O[rows], P.to(BF16).float() @ V, 2e-2, 2e-2, f'{label} ({b},{h}) forward rows')
+        # the stream sums the bf16-ROUNDED probabilities on the matrix pipe: |lse - logsumexp| <= 2^-8 (DESIGN.md round 5)
+        err = float((lse[b, h, rows] - torch.logsumexp(z, -1)).abs().max())
+        assert err < 5e-3, (label, b, h, 'lse', err)
+        dlt = (dO * O).sum(-1)                                                    # [Nq]
+        dS = P * (dO[rows] @ V.t() - dlt[rows, None])
+        ref_dq = dS @ K * scale
+        _close(dq[b, :, sl].float()[rows], ref_dq, 3e-2, 3e-2 * float(ref_dq.abs().max()), f'{label} ({b},{h}) dQ rows')
+        Pk = torch.exp(Q @ K[keys].t() * LN2 - lse[b, h, :, None])                # [Nq, keys] from the kernel's own lse
+        dSk = Pk * (dO @ V[keys].t() - dlt[:, None])
+        ref_dk = dSk.t() @ (Q * LN2)                                              # d z / d K = q_pre ln 2 = q_proj scale
+        ref_dv = Pk.to(BF16).float().t() @ dO
+        _close(dk[b, :, sl].float()[keys], ref_dk, 3e-2, 3e-2 * float(ref_dk.abs().max()), f'{label} ({b},{h}) dK keys')
+        _close(dv[b, :, sl].float()[keys], ref_dv, 3e-2, 3e-2 * float(ref_dv.abs().max()), f'{label} ({b},{h}) dV keys')
+        # rows of P sum to one -> sum over keys of dV = sum over queries of dO (every key block, every chain, the split remainder)
+        a_, b_ = dv[b, :, sl].float().sum(0), dO.sum(0)
+        assert float((a_ - b_).abs().max()) < 2e-2 * float(b_.abs().max()) + 0.5, (label, b, h, float((a_ - b_).abs().max()))
+    return o, lse, dq.clone(), dk.clone(), dv.clone()
+
+
+def test_attention_production_geometry_prescaled(dev):
+    """cfg-3's encoder attention exactly as the step launches it -- B 8 x H 16 = 128 heads at N = 6189, prescaled q, automatic
+    modes: forward stream persistent (3200 query blocks on 512 slots), backward stream with chain 4 + query split + persistent ticket-pulling
+    launch -- against fp32 on sampled rows / keys of four (batch, head) pairs incl. the last head; then the data-parallel geometry (16 CUs
+    reserved for RCCL: 240 workgroups, re-planned chains); both bit-reproducible"""
+    from pixparse_amd import hip, ops
+    B, H, N = 8, 16, N_ENC
+    assert hip.query('crl_attn_bwd_chain_for', N, B * H) == 4 and hip.query('crl_attn_bwd_qsplit_for', N, B * H) == 1
+    pairs = [(0, 0), (3, 5), (5, 11), (7, 15)]
+    first = _attn_prod_check(dev, B, H, N, N, pairs, 21, 'cfg-3 encoder')
+    again = _attn_prod_check(dev, B, H, N, N, pairs[:1], 21, 'cfg-3 encoder (repeat)')
+    for x, y in zip(first, again):
+        assert torch.equal(x, y), 'not reproducible run to run'
+    try:
+        ops.gemm_set_reserved_cus(16)
+        chain16 = hip.query('crl_attn_bwd_chain_for', N, B * H)
+        assert 1 <= chain16 <= 25
+        res = _attn_prod_check(dev, B, H, N, N, pairs, 21, f'cfg-3 encoder, 16 CUs reserved (chain {chain16})')
+    finally:
+        ops.gemm_set_reserved_cus(0)
+    # the forward does not depend on the launch width; dK / dV do not depend on the chain length (only dQ carries the slab roundings)
+    assert torch.equal(res[0], first[0]) and torch.equal(res[1], first[1])
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert rel(res[2], first[2]) < 1e-2 and rel(res[3], first[3]) < 4e-3 and rel(res[4], first[4]) < 4e-3
+
+
+def test_cross_attention_production_geometry_prescaled(dev):
+    """the decoder's cross-attention launch of cfg-3: 1023 queries x 6189 keys, 128 heads, prescaled q, automatic modes"""
+    from pixparse_amd import hip
+    B, H = 8, 16
+    c = hip.query('crl_attn_bwd_chain_for', N_ENC, B * H)
+    _attn_prod_check(dev, B, H, T_DEC, N_ENC, [(0, 3), (7, 15), (4, 8)], 22, f'cfg-3 cross-attention (chain {c})')
+
+
+def test_attention_production_geometry_cfg5_prescaled(dev):
+    """cfg-5's encoder attention as its step launches it: micro-batch 2 x 16 heads at N = 24935 (98 key blocks: the longest chains the policy
+    picks), prescaled q, automatic modes"""
+    from pixparse_amd import hip
+    c = hip.query('crl_attn_bwd_chain_for', 24935, 32)
+    assert c >= 4, c
+    _attn_prod_check(dev, 2, 16, 24935, 24935, [(0, 0), (1, 15)], 23, f'cfg-5 encoder (chain {c})')
+
+
+@pytest.mark.parametrize('policy', [0, 2])
 @pytest.mark.parametrize('N,K,epi', [(4096, 1024, 'gelu'), (1024, 4096, 'resid'), (3072, 1024, 'plain')])
 def test_gemm_full_rows_sampled(dev, N, K, epi, policy):
-    """the step's encoder GEMMs at all 49512 token rows: the automatic plan, the 256x256 kernel alone and the 256x128
-    two-per-CU kernel alone; sampled rows (first / last tile rows included)"""
+    """the step's encoder GEMMs at all 49512 token rows: the automatic plan and the 256x256 kernels alone; sampled rows (first / last
+    tile rows included)"""
     from pixparse_amd import hip, ops
     hip.call('crl_gemm_set_policy', policy)
     try:

@@ -1165,3 +1165,36 @@ def test_gemm_wave_quantisation_cut_decisions():
         assert q(hip.NN, ops.EPI_BF16, M, 1024, 4096) == 0
     finally:
         hip.call('crl_gemm_set_quant_cost', 1.0)
+
+
+def test_every_knob_is_documented_and_tested():
+    """every process-wide entry point (crl_*_set_*) declared in include/crl.h and every PIXPARSE_AMD_* variable the package
+    reads has a line in INTEGRATION.md, and every set_ entry point is flipped by at least one test; nothing documented there is gone from the code"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'crl.h')).read()
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    tests = ''.join(open(f).read() for f in glob.glob(os.path.join(root, 'tests', '*.py')) if not f.endswith('test_host_cpu.py')) + \
+        open(os.path.join(root, 'tests', 'test_host_cpu.py')).read().split('def test_every_knob_is_documented_and_tested')[0]
+    setters = sorted(set(re.findall(r'^int (crl_\w+_set_\w+)\(', header, re.M)))
+    assert len(setters) >= 12, setters
+    for fn in setters:
+        assert f'`{fn}' in doc, f'{fn} has no line in INTEGRATION.md'
+        assert f"'{fn}'" in tests or f'{fn}(' in tests, f'{fn} is not flipped by any test'
+    pkg = ''
+    for dirpath, _, files in os.walk(os.path.join(root, 'pixparse_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                pkg += open(os.path.join(dirpath, f)).read()
+    envs = sorted(set(re.findall(r'PIXPARSE_AMD_[A-Z0-9_]+', pkg)))
+    for e in envs:
+        assert e in doc, f'{e} is read by the package but not documented in INTEGRATION.md'
+    removed = doc.split('Removed in round 6')[1] if 'Removed in round 6' in doc else ''
+    for e in sorted(set(re.findall(r'PIXPARSE_AMD_[A-Z0-9_]+', doc))):
+        if e in removed and e not in doc.split('Removed in round 6')[0]:
+            assert e not in pkg, f'{e} is documented as removed but still read'
+        elif e != 'PIXPARSE_AMD_LIVE_ORACLE':                      # (a switch of the test suite, not of the package)
+            assert e in pkg or e in tests, f'{e} is documented but nothing reads it'
+    for fn in re.findall(r'`(crl_\w+_set_\w+)', removed):
+        assert fn not in header, f'{fn} is documented as removed but still declared'
