@@ -190,7 +190,7 @@ def dominant_kernel_roofline(task, B):
     delta = torch.empty(2, B, H, N, device=qkv.device)
     o2 = torch.empty_like(o)
     lse2 = torch.empty_like(lse)
-    h2, act, pre = T['vit.b0.ln2.y16'], torch.empty_like(T['vit.b0.act']), torch.empty_like(T['vit.b0.pre'])
+    h2, act, pre = T['vit.b0.ln2.y16'], torch.empty_like(T['vit.b0.act']), torch.empty_like(T['vit.b0.dact'])
     w1, b1 = enc.W('blocks.0.mlp.fc1.weight'), enc.P('blocks.0.mlp.fc1.bias')
     cand = {}
     t = time_kernel(lambda: ops.attn_fwd(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], o2.view(B, N, D), lse2, H, scale, False, q_prescaled=True))

@@ -38,8 +38,10 @@ const char* crl_last_error(void);
  * lda/ldb multiples of 8, operands 16-byte aligned and smaller than 4 GiB.
  * epilogue (v = fp32 accumulator, b = bf16-rounded bias, all optional pointers may be NULL):
  *   CRL_EPI_BF16        C(bf16)  = v + b
- *   CRL_EPI_BF16_GELU   aux(bf16)= h = bf16(v + b);  C(bf16) = gelu_erf(h)
- *   CRL_EPI_BF16_DGELU  C(bf16)  = bf16(v) * gelu'(aux)         (aux = saved pre-activation h, bf16)
+ *   CRL_EPI_BF16_GELU   h = bf16(v + b);  C(bf16) = gelu_erf(h);  aux(fp16) = gelu_erf'(h)   (saved for the backward: one erf serves both)
+ *   CRL_EPI_BF16_DGELU  C(bf16)  = bf16(v) * aux                (aux = the derivative the forward saved, fp16 -- torch's gelu_backward
+ *                       evaluates gelu'(h) again from the saved h; here it is rounded once to fp16, 2^-11 relative, a quarter of the
+ *                       bf16 rounding of the product)
  *   CRL_EPI_F32_RESID   C(f32)   = resid(f32) + float(bf16(v + b))   (resid may alias C)
  *   CRL_EPI_F32         C(f32)   = v            (beta = 0)
  *   CRL_EPI_F32_ACC     C(f32)  += v            (beta = 1: grad accumulation)

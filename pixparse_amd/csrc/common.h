@@ -66,12 +66,6 @@ __device__ __forceinline__ float gelu_f(float x) {
   erf_parts(x, e, g);
   return 0.5f * x * (1.0f + e);
 }
-__device__ __forceinline__ float dgelu_f(float x) {
-  float e, g;
-  erf_parts(x, e, g);
-  return __builtin_fmaf(x * 0.39894228040143268f, g, 0.5f * (1.0f + e));
-}
-
 // Two elements at a time on the packed-fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): the GEMM epilogues run 128 of
 // these per lane with the matrix pipe idle, and the s_memtime timeline of the persistent kernel shows the GELU / dGELU epilogues
 // bound by VALU issue (about 124 clocks per element in the scalar form: ~21 simple ops + rcp + exp2).  Same formulas as above
@@ -90,16 +84,31 @@ __device__ __forceinline__ void erf_parts2(f32x2 x, f32x2& erf_v, f32x2& gauss) 
   const f32x2 e = 1.0f - (p * t) * gauss;
   erf_v.x = copysignf(e.x, x.x); erf_v.y = copysignf(e.y, x.y);
 }
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+// gelu(x) AND gelu'(x) = Phi(x) + x phi(x) from one erf / gauss evaluation (round 6: the forward epilogue saves the derivative, the
+// backward epilogue only multiplies -- include/crl.h CRL_EPI_BF16_GELU / _DGELU): two packed operations more than gelu alone
+__device__ __forceinline__ void gelu_grad2(f32x2 x, f32x2& y, f32x2& d) {
   f32x2 e, g;
   erf_parts2(x, e, g);
-  return (x * 0.5f) * (e + 1.0f);
+  const f32x2 cdf = (e + 1.0f) * 0.5f;       // (scaling by 0.5 is exact: x * cdf == (x * 0.5) * (e + 1) bit for bit)
+  y = x * cdf;
+  d = (x * 0.39894228040143268f) * g + cdf;
 }
-__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
-  f32x2 e, g;
-  erf_parts2(x, e, g);
-  return (x * 0.39894228040143268f) * g + (e + 1.0f) * 0.5f;
+__device__ __forceinline__ void gelu_grad_f(float x, float& y, float& d) {
+  float e, g;
+  erf_parts(x, e, g);
+  const float cdf = 0.5f * (1.0f + e);
+  y = x * cdf;
+  d = __builtin_fmaf(x * 0.39894228040143268f, g, cdf);
 }
+// the saved derivative travels as IEEE fp16 (round to nearest even): gelu' lies in [-0.13, 1.13], so fp16's 11 significant bits give it a
+// relative rounding of 2^-11, a quarter of the bf16 rounding the product dy * gelu'(h) gets anyway (a bf16 copy would double that
+// tensor's rounding noise); below 6e-5 fp16 goes subnormal: absolute error <= 3e-8
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { const f16x2 r = {(_Float16)lo, (_Float16)hi}; return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ uint32_t pack_h2v(f32x2 v) { return pack_h2(v.x, v.y); }
+__device__ __forceinline__ f32x2 unpack_h2(uint32_t w) { const f16x2 r = __builtin_bit_cast(f16x2, w); return f32x2{(float)r.x, (float)r.y}; }
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return unpack_h2(w).x; }
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return unpack_h2(w).y; }
 // bf16 pair <-> two floats: one v_cvt_pk_bf16_f32 / one shift + one mask
 __device__ __forceinline__ uint32_t pack_bf2v(f32x2 v) { return pack_bf2(v.x, v.y); }
 __device__ __forceinline__ f32x2 unpack_bf2(uint32_t w) { f32x2 r; r.x = __uint_as_float(w << 16); r.y = __uint_as_float(w & 0xffff0000u); return r; }

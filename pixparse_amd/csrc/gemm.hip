@@ -114,14 +114,13 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_kernel(const GemmArgs g) {
       } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
         float h[4], y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
-        *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+        for (int r = 0; r < 4; ++r) gelu_grad_f(round_bf(v[r]), y[r], h[r]);      // h := gelu'(bf16(v + b)), saved as fp16
+        *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
         *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
       } else if constexpr (EPI == CRL_EPI_BF16_DGELU) {
         const uint2 hh = *reinterpret_cast<const uint2*>((const u16*)g.aux + (size_t)m * g.ldaux + n);
-        const float h0 = bf2f(hh.x & 0xffff), h1 = bf2f(hh.x >> 16), h2 = bf2f(hh.y & 0xffff), h3 = bf2f(hh.y >> 16);
-        const float y0 = round_bf(v[0]) * dgelu_f(h0), y1 = round_bf(v[1]) * dgelu_f(h1);
-        const float y2 = round_bf(v[2]) * dgelu_f(h2), y3 = round_bf(v[3]) * dgelu_f(h3);
+        const float y0 = round_bf(v[0]) * h2f_lo(hh.x), y1 = round_bf(v[1]) * h2f_hi(hh.x);
+        const float y2 = round_bf(v[2]) * h2f_lo(hh.y), y3 = round_bf(v[3]) * h2f_hi(hh.y);
         *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y0, y1), pack_bf2(y2, y3)};
       } else if constexpr (EPI == CRL_EPI_F32_RESID) {
         const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);

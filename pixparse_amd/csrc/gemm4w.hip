@@ -68,7 +68,7 @@ __device__ __forceinline__ void epilogue4w(const GemmArgs& g, f32x4 (&c)[8][8], 
     const uint32_t rstepA = 16u * (uint32_t)g.ldaux * 2u;
     auto offC = [&](int i, int pr) { return okc[pr] ? cC[pr] + (uint32_t)i * rstepC : nrecC; };
     auto offA = [&](int i, int pr) { return okc[pr] ? cA[pr] + (uint32_t)i * rstepA : nrecA; };
-    // saved pre-activations of the dGELU epilogue: ALL thirty-two 16-byte loads of the lane go out before the first store (a load behind a
+    // saved derivatives of the dGELU epilogue: ALL thirty-two 16-byte loads of the lane go out before the first store (a load behind a
     // store would wait for its write acknowledgement); hw[8 i' + t] belongs to row group i, strip pair pr with 4 i + pr = index
     epi_u4 hw[32];
     if constexpr (EPI == CRL_EPI_BF16_DGELU) {
@@ -92,23 +92,24 @@ __device__ __forceinline__ void epilogue4w(const GemmArgs& g, f32x4 (&c)[8][8], 
         swap_strips(x0, x1, y0, y1);
         epi_st(rC, offC(i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
       } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
-        // h = bf16(v + b) is stored as is and expanded back to fp32 for the activation (the rounding the reference's autocast applies)
-        const uint32_t h00 = pack_bf2v(v[0][0]), h01 = pack_bf2v(v[0][1]), h10 = pack_bf2v(v[1][0]), h11 = pack_bf2v(v[1][1]);
-        x0 = h00; x1 = h01; y0 = h10; y1 = h11;
+        // h = bf16(v + b) (the rounding the reference's autocast applies) -> gelu(h) and, saved for the backward as fp16, gelu'(h)
+        f32x2 ga[4], da[4];
+        gelu_grad2(unpack_bf2(pack_bf2v(v[0][0])), ga[0], da[0]); gelu_grad2(unpack_bf2(pack_bf2v(v[0][1])), ga[1], da[1]);
+        gelu_grad2(unpack_bf2(pack_bf2v(v[1][0])), ga[2], da[2]); gelu_grad2(unpack_bf2(pack_bf2v(v[1][1])), ga[3], da[3]);
+        x0 = pack_h2v(da[0]); x1 = pack_h2v(da[1]); y0 = pack_h2v(da[2]); y1 = pack_h2v(da[3]);
         swap_strips(x0, x1, y0, y1);
         epi_st_saved(rA, offA(i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
-        x0 = pack_bf2v(gelu2(unpack_bf2(h00))); x1 = pack_bf2v(gelu2(unpack_bf2(h01)));
-        y0 = pack_bf2v(gelu2(unpack_bf2(h10))); y1 = pack_bf2v(gelu2(unpack_bf2(h11)));
+        x0 = pack_bf2v(ga[0]); x1 = pack_bf2v(ga[1]); y0 = pack_bf2v(ga[2]); y1 = pack_bf2v(ga[3]);
         swap_strips(x0, x1, y0, y1);
         epi_st(rC, offC(i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
-      } else {   // dGELU: the 16-byte load holds 8 consecutive saved pre-activations; the exchange (an involution) returns this lane's own
+      } else {   // dGELU: the 16-byte load holds 8 consecutive saved derivatives (fp16); the exchange (an involution) returns this lane's own
         const epi_u4 hm = L.to_math(hw[u]);
         uint32_t a0 = hm[0], a1 = hm[1], b0 = hm[2], b1 = hm[3];
         swap_strips(a0, a1, b0, b1);
-        x0 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][0])) * dgelu2(unpack_bf2(a0)));
-        x1 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][1])) * dgelu2(unpack_bf2(a1)));
-        y0 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][0])) * dgelu2(unpack_bf2(b0)));
-        y1 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][1])) * dgelu2(unpack_bf2(b1)));
+        x0 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][0])) * unpack_h2(a0));
+        x1 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][1])) * unpack_h2(a1));
+        y0 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][0])) * unpack_h2(b0));
+        y1 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][1])) * unpack_h2(b1));
         swap_strips(x0, x1, y0, y1);
         epi_st(rC, offC(i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
       }

@@ -141,7 +141,7 @@ __device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc
     const uint32_t rstepA = 16u * (uint32_t)g.ldaux * 2u;
     auto offC = [&](int qm, int i, int pr) { return okc[pr] ? cC[pr] + (uint32_t)(8 * qm + i) * rstepC : nrecC; };
     auto offA = [&](int qm, int i, int pr) { return okc[pr] ? cA[pr] + (uint32_t)(8 * qm + i) * rstepA : nrecA; };
-    // saved pre-activations of the dGELU epilogue: ALL sixteen 16-byte loads of the lane are issued before the first use (64 VGPRs; the
+    // saved derivatives of the dGELU epilogue: ALL sixteen 16-byte loads of the lane are issued before the first use (64 VGPRs; the
     // operand fragments of the K loop are dead here) -- one memory round trip per tile instead of one per batch.  Loads issued between
     // the stores would also be counted behind them (vmcnt retires in issue order), i.e. wait for write acknowledgements.
     epi_u4 hw[4][4];
@@ -171,23 +171,25 @@ __device__ __forceinline__ void epilogue_tile_buf(const GemmArgs& g, f32x4 (&acc
           swap_strips(x0, x1, y0, y1);
           epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
         } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
-          // h = bf16(v + b) is stored as is and expanded back to fp32 for the activation (the rounding the reference's autocast applies)
-          const uint32_t h00 = pack_bf2v(v[0][0]), h01 = pack_bf2v(v[0][1]), h10 = pack_bf2v(v[1][0]), h11 = pack_bf2v(v[1][1]);
-          x0 = h00; x1 = h01; y0 = h10; y1 = h11;
+          // h = bf16(v + b) (the rounding the reference's autocast applies) is expanded back to fp32 for the activation; what is SAVED for the
+          // backward is gelu'(h) as fp16 (one erf / gauss evaluation serves both), so that the dgrad epilogue only multiplies
+          f32x2 ga[4], da[4];
+          gelu_grad2(unpack_bf2(pack_bf2v(v[0][0])), ga[0], da[0]); gelu_grad2(unpack_bf2(pack_bf2v(v[0][1])), ga[1], da[1]);
+          gelu_grad2(unpack_bf2(pack_bf2v(v[1][0])), ga[2], da[2]); gelu_grad2(unpack_bf2(pack_bf2v(v[1][1])), ga[3], da[3]);
+          x0 = pack_h2v(da[0]); x1 = pack_h2v(da[1]); y0 = pack_h2v(da[2]); y1 = pack_h2v(da[3]);
           swap_strips(x0, x1, y0, y1);
           epi_st_saved(rA, offA(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
-          x0 = pack_bf2v(gelu2(unpack_bf2(h00))); x1 = pack_bf2v(gelu2(unpack_bf2(h01)));
-          y0 = pack_bf2v(gelu2(unpack_bf2(h10))); y1 = pack_bf2v(gelu2(unpack_bf2(h11)));
+          x0 = pack_bf2v(ga[0]); x1 = pack_bf2v(ga[1]); y0 = pack_bf2v(ga[2]); y1 = pack_bf2v(ga[3]);
           swap_strips(x0, x1, y0, y1);
           epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
-        } else {   // dGELU: the 16-byte load holds 8 consecutive saved pre-activations; the exchange (an involution) returns this lane's own
+        } else {   // dGELU: the 16-byte load holds 8 consecutive saved derivatives (fp16); the exchange (an involution) returns this lane's own
           const epi_u4 hm = L.to_math(hw[b][t]);
           uint32_t a0 = hm[0], a1 = hm[1], b0 = hm[2], b1 = hm[3];
           swap_strips(a0, a1, b0, b1);
-          x0 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][0])) * dgelu2(unpack_bf2(a0)));
-          x1 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][1])) * dgelu2(unpack_bf2(a1)));
-          y0 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][0])) * dgelu2(unpack_bf2(b0)));
-          y1 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][1])) * dgelu2(unpack_bf2(b1)));
+          x0 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][0])) * unpack_h2(a0));
+          x1 = pack_bf2v(unpack_bf2(pack_bf2v(v[0][1])) * unpack_h2(a1));
+          y0 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][0])) * unpack_h2(b0));
+          y1 = pack_bf2v(unpack_bf2(pack_bf2v(v[1][1])) * unpack_h2(b1));
           swap_strips(x0, x1, y0, y1);
           epi_st(rC, offC(qm, i, pr), L.to_access(epi_u4{x0, x1, y0, y1}));
         }
@@ -302,16 +304,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
         } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
           float h[4], y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
+          for (int r = 0; r < 4; ++r) gelu_grad_f(round_bf(v[r]), y[r], h[r]);      // h := gelu'(bf16(v + b)), saved as fp16
           if (ok[c4]) {
-            *reinterpret_cast<uint2*>((u16*)g.aux + mc * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+            *reinterpret_cast<uint2*>((u16*)g.aux + mc * g.ldaux + n) = uint2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
             *reinterpret_cast<uint2*>((u16*)g.C + mc * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
           }
         } else if constexpr (EPI == CRL_EPI_BF16_DGELU) {
           const uint2 hh = hv[c4];
-          const float h0 = bf2f(hh.x & 0xffff), h1 = bf2f(hh.x >> 16), h2 = bf2f(hh.y & 0xffff), h3 = bf2f(hh.y >> 16);
-          const float y0 = round_bf(v[0]) * dgelu_f(h0), y1 = round_bf(v[1]) * dgelu_f(h1);
-          const float y2 = round_bf(v[2]) * dgelu_f(h2), y3 = round_bf(v[3]) * dgelu_f(h3);
+          const float y0 = round_bf(v[0]) * h2f_lo(hh.x), y1 = round_bf(v[1]) * h2f_hi(hh.x);
+          const float y2 = round_bf(v[2]) * h2f_lo(hh.y), y3 = round_bf(v[3]) * h2f_hi(hh.y);
           if (ok[c4]) *reinterpret_cast<uint2*>((u16*)g.C + mc * g.ldc + n) = uint2{pack_bf2(y0, y1), pack_bf2(y2, y3)};
         } else if constexpr (EPI == CRL_EPI_F32_RESID) {
           const float4 r = rv[c4];
@@ -403,26 +404,26 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
 #pragma unroll
               for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { h[j][r] = round_bf(v[j][r]); y[j][r] = gelu_f(h[j][r]); }
-              x0 = pack_bf2(h[0][0], h[0][1]); x1 = pack_bf2(h[0][2], h[0][3]);
-              y0 = pack_bf2(h[1][0], h[1][1]); y1 = pack_bf2(h[1][2], h[1][3]);
+                for (int r = 0; r < 4; ++r) gelu_grad_f(round_bf(v[j][r]), y[j][r], h[j][r]);      // h := gelu'(bf16(v + b)), saved as fp16
+              x0 = pack_h2(h[0][0], h[0][1]); x1 = pack_h2(h[0][2], h[0][3]);
+              y0 = pack_h2(h[1][0], h[1][1]); y1 = pack_h2(h[1][2], h[1][3]);
               swap_strips(x0, x1, y0, y1);
               if (ok[pr]) *reinterpret_cast<uint4*>((u16*)g.aux + mc * g.ldaux + nw[pr]) = uint4{x0, x1, y0, y1};
               x0 = pack_bf2(y[0][0], y[0][1]); x1 = pack_bf2(y[0][2], y[0][3]);
               y0 = pack_bf2(y[1][0], y[1][1]); y1 = pack_bf2(y[1][2], y[1][3]);
               swap_strips(x0, x1, y0, y1);
               if (ok[pr]) *reinterpret_cast<uint4*>(crow) = uint4{x0, x1, y0, y1};
-            } else {   // CRL_EPI_BF16_DGELU: the 16-byte load holds 8 consecutive saved pre-activations; the exchange returns this lane's own
+            } else {   // CRL_EPI_BF16_DGELU: the 16-byte load holds 8 consecutive saved derivatives (fp16); the exchange returns this lane's own
               uint32_t a0 = hw[pr].x, a1 = hw[pr].y, b0 = hw[pr].z, b1 = hw[pr].w;
               swap_strips(a0, a1, b0, b1);
               const uint32_t hh[2][2] = {{a0, a1}, {b0, b1}};
               float y[2][4];
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                y[j][0] = round_bf(v[j][0]) * dgelu_f(bf2f(hh[j][0] & 0xffff));
-                y[j][1] = round_bf(v[j][1]) * dgelu_f(bf2f(hh[j][0] >> 16));
-                y[j][2] = round_bf(v[j][2]) * dgelu_f(bf2f(hh[j][1] & 0xffff));
-                y[j][3] = round_bf(v[j][3]) * dgelu_f(bf2f(hh[j][1] >> 16));
+                y[j][0] = round_bf(v[j][0]) * h2f_lo(hh[j][0]);
+                y[j][1] = round_bf(v[j][1]) * h2f_hi(hh[j][0]);
+                y[j][2] = round_bf(v[j][2]) * h2f_lo(hh[j][1]);
+                y[j][3] = round_bf(v[j][3]) * h2f_hi(hh[j][1]);
               }
               x0 = pack_bf2(y[0][0], y[0][1]); x1 = pack_bf2(y[0][2], y[0][3]);
               y0 = pack_bf2(y[1][0], y[1][1]); y1 = pack_bf2(y[1][2], y[1][3]);
@@ -461,8 +462,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, f32x4 (&acc)[2]
           } else if constexpr (EPI == CRL_EPI_BF16_GELU) {
             float h[4], y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { h[r] = round_bf(v[r]); y[r] = gelu_f(h[r]); }
-            *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+            for (int r = 0; r < 4; ++r) gelu_grad_f(round_bf(v[r]), y[r], h[r]);      // h := gelu'(bf16(v + b)), saved as fp16
+            *reinterpret_cast<uint2*>((u16*)g.aux + (size_t)m * g.ldaux + n) = uint2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
             *reinterpret_cast<uint2*>((u16*)g.C + (size_t)m * g.ldc + n) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
           } else {   // CRL_EPI_F32: split-K slab
             *reinterpret_cast<float4*>((float*)g.C + slab_off + (size_t)m * g.ldc + n) = float4{v[0], v[1], v[2], v[3]};

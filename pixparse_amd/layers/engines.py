@@ -20,7 +20,7 @@ import os
 import torch
 
 from .. import ops
-from ..ops import BF16, F32, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC
+from ..ops import BF16, F16, F32, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC
 from .arena import ParamArena
 
 
@@ -177,7 +177,7 @@ class ViTEngine(_Base):
             x2 = self.buf(k + '.x2', (M, D), F32)
             ops.linear_fwd(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, EPI_F32_RESID, resid=x)
             _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
-            pre = self.buf(k + '.pre', (M, F_), BF16)
+            pre = self.buf(k + '.dact', (M, F_), F16)     # gelu'(fc1 output), saved by the GELU epilogue for the fc2 dgrad epilogue
             act = self.buf(k + '.act', (M, F_), BF16)
             ops.linear_fwd(h2, self.W(bp + 'mlp.fc1.weight'), self.P(bp + 'mlp.fc1.bias'), act, EPI_BF16_GELU, aux=pre)
             x3 = self.buf(k + '.x3', (M, D), F32)
@@ -214,7 +214,7 @@ class ViTEngine(_Base):
             xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
             h1, h2 = T[tg + k + '.ln1.y16'], T[tg + k + '.ln2.y16']
             qkv, o, lse = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.lse']
-            pre, act = T[tg + k + '.pre'], T[tg + k + '.act']
+            pre, act = T[tg + k + '.dact'], T[tg + k + '.act']
             # ---- MLP: x3 = x2 + fc2(gelu(fc1(LN2(x2))));  gb = bf16(dx3)
             # (the bias gradients of fc2 / attn.proj = column sums of gb were accumulated by the LayerNorm backward that wrote gb)
             ops.linear_dgrad(gb, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
@@ -369,7 +369,7 @@ class SwinEngine(_Base):
                 x2 = self.buf(k + '.x2', (M, C), F32)
                 self._join(o, self.W(bp + 'attn.proj.weight'), self.P(bp + 'attn.proj.bias'), x2, x, k + '.dps1', gj, 0, Hf * Wf)
                 _, h2 = self.ln_fwd(bp + 'norm2', x2, k + '.ln2', eps)
-                pre = self.buf(k + '.pre', (M, F_), BF16)
+                pre = self.buf(k + '.dact', (M, F_), F16)     # gelu'(fc1 output), saved by the GELU epilogue for the fc2 dgrad epilogue
                 act = self.buf(k + '.act', (M, F_), BF16)
                 ops.linear_fwd(h2, self.W(bp + 'mlp.fc1.weight'), self.P(bp + 'mlp.fc1.bias'), act, EPI_BF16_GELU, aux=pre)
                 x3 = self.buf(k + '.x3', (M, C), F32)
@@ -404,7 +404,7 @@ class SwinEngine(_Base):
                 shift = 0 if (bi % 2 == 0 or w >= min(Hf, Wf)) else w // 2
                 xin, x2 = T[tg + k + '.xin'], T[tg + k + '.x2']
                 h1, h2 = T[tg + k + '.ln1.y16'], T[tg + k + '.ln2.y16']
-                qkv, o, pre, act = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.pre'], T[tg + k + '.act']
+                qkv, o, pre, act = T[tg + k + '.qkv'], T[tg + k + '.o'], T[tg + k + '.dact'], T[tg + k + '.act']
                 gj = gj_end + bi
                 gm = self._branch_grad(gb, k + '.dps2', gj, Hf * Wf, f'gbs{si}')      # d(MLP branch output) = drop-path scale o d(x3)
                 ops.linear_dgrad(gm, self.W(bp + 'mlp.fc2.weight'), dpre, EPI_BF16_DGELU, aux=pre)
@@ -587,7 +587,7 @@ class BartEngine(_Base):
             t2 = self.buf(k + '.t2', (M, D), F32)
             self._branch(o2, self.W(lp + 'encoder_attn.out_proj.weight'), self.P(lp + 'encoder_attn.out_proj.bias'), t2, h1, 2 + 3 * i)
             h2, h2b = self.ln_fwd(lp + 'encoder_attn_layer_norm', t2, k + '.ln2', eps, True, True)
-            pre = self.buf(k + '.pre', (M, F_), BF16)
+            pre = self.buf(k + '.dact', (M, F_), F16)     # gelu'(fc1 output), saved by the GELU epilogue for the fc2 dgrad epilogue
             act = self.buf(k + '.act', (M, F_), BF16)
             ops.linear_fwd(h2b, self.W(lp + 'fc1.weight'), self.P(lp + 'fc1.bias'), act, EPI_BF16_GELU, aux=pre)
             if p_act:
@@ -607,7 +607,7 @@ class BartEngine(_Base):
         if x.shape[0] <= ops.SKINNY_MAX_ROWS:
             ops.linear_skinny(x, w, b, out, epi, resid=resid)
         else:
-            aux = self.buf('gen.gelu_pre', out.shape, BF16) if epi == EPI_BF16_GELU else None   # the GEMM epilogue also stores the pre-activation
+            aux = self.buf('gen.gelu_dact', out.shape, F16) if epi == EPI_BF16_GELU else None   # the GEMM epilogue also stores gelu'(h) (unused here)
             ops.linear_fwd(x, w, b, out, epi, aux=aux, resid=resid)
 
     def _ln_lin(self, ln_name, t32, key, eps, w, b, out, epi=ops.EPI_BF16, **row):
@@ -769,7 +769,7 @@ class BartEngine(_Base):
             g = lambda n: Tb[tg + k + n]
             # ---- h_out = LN3(t3), t3 = h2 + fc2(gelu(fc1(h2b)))
             self._branch_bwd(lp + 'final_layer_norm', k + '.ln3', g('.t3'), dy32, dyb, dt, dtb, lp + 'fc2', 3 + 3 * i)
-            ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.pre'))
+            ops.linear_dgrad(dtb, self.W(lp + 'fc2.weight'), dpre, EPI_BF16_DGELU, aux=g('.dact'))
             if p_act:
                 ops.dropout(dpre, dpre, drop, 300 + i, p=p_act)    # mask o scale and gelu' are both elementwise: applied behind the fused dGELU epilogue
             self.lin_wgrad(lp + 'fc2', dtb, g('.act'), has_bias=False)

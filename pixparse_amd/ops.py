@@ -8,7 +8,7 @@ import torch
 from . import hip
 from .hip import NT, NN, TN, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC  # noqa: F401
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 VOCAB_PAD = 128   # logits row stride / embedding rows are padded to a multiple of this
 K_PAD = 64        # contraction dims of NT/NN GEMMs are padded to a multiple of this when needed
 

@@ -197,11 +197,13 @@ def _gemm_full_rows(dev, N, K, epi):
     rows = torch.cat([torch.randperm(M, generator=torch.Generator().manual_seed(2))[:125], torch.tensor([0, M - 1, 49407])]).to(dev)
     ref = x[rows].float() @ w.float().t() + bias.to(BF16).float()
     if epi == 'gelu':
-        pre = torch.empty(M, N, dtype=BF16, device=dev)
+        dact = torch.empty(M, N, dtype=torch.float16, device=dev)      # gelu'(h) saved for the backward (fp16)
         act = torch.empty(M, N, dtype=BF16, device=dev)
-        ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=pre)
-        _close(pre[rows], ref, 1e-2, 1e-2, 'fc1 pre')
-        _close(act[rows], torch.nn.functional.gelu(pre[rows].float()), 1e-2, 1e-3, 'fc1 gelu')
+        ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=dact)
+        h = ref.to(BF16).double()
+        dref = 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
+        _close(dact[rows], dref.float(), 1e-2, 1e-2, 'fc1 saved gelu derivative')
+        _close(act[rows], torch.nn.functional.gelu(h).float(), 1e-2, 1e-2, 'fc1 gelu')
     elif epi == 'resid':
         resid = _rnd((M, N), dev, 1.0, 4)
         want = resid[rows] + ref.to(BF16).float()

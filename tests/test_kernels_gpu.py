@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 
 
 @pytest.fixture(scope='module')
@@ -25,6 +25,12 @@ def dev():
 def rnd(shape, dev, scale=1.0, seed=0, dtype=F32):
     g = torch.Generator(device='cpu').manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def gelu_grad_ref(h):
+    """erf-GELU derivative Phi(h) + h phi(h), evaluated in fp64 (what the GELU epilogue saves as fp16 and the dgrad epilogue multiplies by)"""
+    h64 = h.double()
+    return (0.5 * (1.0 + torch.erf(h64 / math.sqrt(2.0))) + h64 * torch.exp(-0.5 * h64 * h64) / math.sqrt(2.0 * math.pi)).float()
 
 
 def close(a, b, rtol, atol, what=''):
@@ -400,12 +406,19 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     out = torch.empty(M, N, dtype=BF16, device=dev)
     ops.linear_fwd(x, w, bias, out)
     close(out, ref, 1e-2, 1e-2, 'EPI_BF16')           # bf16 output rounding: 2^-8 relative
-    # GELU epilogue: aux = pre-activation, out = gelu(bf16(pre))
-    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    # GELU epilogue: h = bf16(v + b), out = gelu(h), aux = gelu'(h) as fp16 (h itself may differ from torch's by a bf16 ulp: summation order)
+    dact = torch.empty(M, N, dtype=F16, device=dev)
     act = torch.empty(M, N, dtype=BF16, device=dev)
-    ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=pre)
-    close(pre, ref, 1e-2, 1e-2, 'GELU aux')
-    close(act, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, 'GELU out')
+    ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=dact)
+    h = ref.to(BF16).float()
+    close(dact, gelu_grad_ref(h), 1e-2, 1e-2, 'GELU aux')
+    close(act, torch.nn.functional.gelu(h), 1e-2, 1e-2, 'GELU out')
+    # ... and EXACTLY: with x = 0 the pre-activation is bf16(bias), known bit for bit -> gelu to a bf16 ulp, gelu' to an fp16 ulp, over [-9, 9]
+    bsweep = torch.linspace(-9.0, 9.0, N, device=dev)
+    ops.linear_fwd(torch.zeros_like(x), w, bsweep, act, ops.EPI_BF16_GELU, aux=dact)
+    hb = bsweep.to(BF16).float().expand(M, N)
+    close(act, torch.nn.functional.gelu(hb.double()).float(), 2.0 ** -8, 1e-6, 'GELU out (exact h)')
+    close(dact, gelu_grad_ref(hb), 2.0 ** -10, 1e-6, 'GELU aux (exact h)')
     # residual epilogue (fp32 out, in place on the residual)
     resid = rnd((M, N), dev, 1.0, 4)
     want = resid + ref.to(BF16).float()
@@ -497,7 +510,7 @@ def test_gemm_nn_dgrad(dev, M, N, K):
     h = rnd((M, K), dev, 1.0, 3, BF16)
     hf = h.float().requires_grad_(True)
     torch.nn.functional.gelu(hf).backward(ref.to(BF16).float())
-    ops.linear_dgrad(dy, w, out, ops.EPI_BF16_DGELU, aux=h)
+    ops.linear_dgrad(dy, w, out, ops.EPI_BF16_DGELU, aux=gelu_grad_ref(h.float()).to(F16))      # aux = the derivative the forward saved
     close(out, hf.grad, 1e-2, 1e-2, 'NN + dGELU')
     acc = rnd((M, K), dev, 1.0, 5)
     want = acc + ref
@@ -548,13 +561,13 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy, big):
     hip.call('crl_gemm_set_policy', policy)
     try:
         out = torch.empty(M, N, dtype=BF16, device=dev)
-        pre = torch.empty(M, N, dtype=BF16, device=dev)
+        pre = torch.empty(M, N, dtype=F16, device=dev)
         ops.linear_fwd(x, w, bias, out)
         close(out, x.float() @ w.float().t() + bias.to(BF16).float(), 1e-2, 1e-2, '256 NT bf16')
         ops.linear_fwd(x, w, bias, out, ops.EPI_BF16_GELU, aux=pre)
         ref = x.float() @ w.float().t() + bias.to(BF16).float()
-        close(pre, ref, 1e-2, 1e-2, '256 NT aux')
-        close(out, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, '256 NT gelu')
+        close(pre, gelu_grad_ref(ref.to(BF16).float()), 1e-2, 1e-2, '256 NT aux')
+        close(out, torch.nn.functional.gelu(ref.to(BF16).float()), 1e-2, 1e-2, '256 NT gelu')
         y = rnd((M, N), dev, 1.0, 5)
         want = y + ref.to(BF16).float()
         ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
@@ -567,7 +580,7 @@ def test_gemm_256_kernel_all_layouts(dev, K, policy, big):
             h = rnd((M, K), dev, 1.0, 6, BF16)
             hf = h.float().requires_grad_(True)
             torch.nn.functional.gelu(hf).backward((dyc.float() @ wc.float()).to(BF16).float())
-            ops.linear_dgrad(dyc, wc, dx, ops.EPI_BF16_DGELU, aux=h)
+            ops.linear_dgrad(dyc, wc, dx, ops.EPI_BF16_DGELU, aux=gelu_grad_ref(h.float()).to(F16))
             close(dx, hf.grad, 1e-2, 2e-2, '256 NN + dGELU')
             accb = rnd((M, K), dev, 1.0, 7)
             wantb = accb + dyc.float() @ wc.float()
@@ -594,7 +607,7 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
     dy = rnd((M, N), dev, 1.0, 4, BF16)
-    h = rnd((M, K), dev, 1.0, 6, BF16)
+    h = gelu_grad_ref(rnd((M, K), dev, 1.0, 6, BF16).float()).to(F16)       # a saved GELU derivative (fp16)
     y0 = rnd((M, N), dev, 1.0, 5)
     acc0 = rnd((M, K), dev, 1.0, 7)
     NC = N - N % 32                      # NN: the contraction (N) must be a multiple of 32
@@ -602,7 +615,7 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
     CS = min(N, 328)                     # column-scale boundary INSIDE a 256-column tile (and not on a 16-column strip pair: 328 = 256 + 72)
 
     def run():
-        out = torch.empty(M, N, dtype=BF16, device=dev); pre = torch.empty(M, N, dtype=BF16, device=dev); g = torch.empty(M, N, dtype=BF16, device=dev)
+        out = torch.empty(M, N, dtype=BF16, device=dev); pre = torch.empty(M, N, dtype=F16, device=dev); g = torch.empty(M, N, dtype=BF16, device=dev)
         ops.linear_fwd(x, w, bias, out, colscale=0.25, colscale_cols=CS)
         ops.linear_fwd(x, w, bias, g, ops.EPI_BF16_GELU, aux=pre)
         y = y0.clone()
@@ -796,11 +809,11 @@ def _quant_split_case(dev, M, N, K):
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
     ref = x.float() @ w.float().t() + bias.to(BF16).float()
-    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    pre = torch.empty(M, N, dtype=F16, device=dev)
     act = torch.empty(M, N, dtype=BF16, device=dev)
     ops.linear_fwd(x, w, bias, act, ops.EPI_BF16_GELU, aux=pre)
-    close(pre, ref, 1e-2, 1e-2, 'split aux')
-    close(act, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-3, 'split gelu')
+    close(pre, gelu_grad_ref(ref.to(BF16).float()), 1e-2, 1e-2, 'split aux')
+    close(act, torch.nn.functional.gelu(ref.to(BF16).float()), 1e-2, 1e-2, 'split gelu')
     y = rnd((M, N), dev, 1.0, 4)
     want = y + ref.to(BF16).float()
     ops.linear_fwd(x, w, bias, y, ops.EPI_F32_RESID, resid=y)
