@@ -65,6 +65,16 @@ if __name__ == '__main__':
         case(f'{tag} dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, rounds=1)
         case(f'{tag} dgrad proj', 'NN', M, 1024, 1024, rounds=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dgelu4':    # the fc2 dgrad shape: plain store against the dGELU (multiply by the saved derivative) epilogue, with / without the wave-quantisation cut
+        tag = os.path.basename(os.environ.get('PIXPARSE_AMD_LIB', 'product'))
+        for pol in (0, 2):
+            case(f'{tag} dgrad fc2 plain', 'NN', M, 1024, 4096, ops.EPI_BF16, policy=pol, rounds=1)
+            case(f'{tag} dgrad fc2 dgelu', 'NN', M, 1024, 4096, ops.EPI_BF16_DGELU, policy=pol, rounds=1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'decdgelu':    # the decoder's fc2 dgrad + dGELU (8184 rows: two rounds of tiles, classic forms only)
+        case('dec dgrad fc2 dgelu', 'NN', 8184, 1024, 4096, ops.EPI_BF16_DGELU, rounds=2)
+        case('dec fc1 gelu', 'NT', 8184, 4096, 1024, ops.EPI_BF16_GELU, rounds=2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'epi2x':    # the epilogue-heavy launches: automatic plan (8-wave 256x256) against the 256x128 two-per-CU kernel (policy 3)
         for pol in (0, 3, 0, 3):
             case(f'fc1 gelu pol {pol}', 'NT', M, 4096, 1024, ops.EPI_BF16_GELU, policy=pol, rounds=1)

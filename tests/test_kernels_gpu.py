@@ -607,7 +607,7 @@ def test_gemm_4w_kernel_bit_identical_to_8w(dev, M, N, K):
     w = rnd((N, K), dev, 0.1, 2, BF16)
     bias = rnd((N,), dev, 0.5, 3)
     dy = rnd((M, N), dev, 1.0, 4, BF16)
-    h = gelu_grad_ref(rnd((M, K), dev, 1.0, 6, BF16).float()).to(F16)       # a saved GELU derivative (fp16)
+    h = gelu_grad_ref(rnd((M, K), dev, 3.0, 6, BF16).float()).to(F16)       # a saved GELU derivative (fp16; pre-activations out to |h| ~ 12: fp16 subnormals and -0.0 included)
     y0 = rnd((M, N), dev, 1.0, 5)
     acc0 = rnd((M, K), dev, 1.0, 7)
     NC = N - N % 32                      # NN: the contraction (N) must be a multiple of 32
