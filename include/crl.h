@@ -163,7 +163,12 @@ int crl_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64
 /* q_prescaled = 1: q holds q * scale * log2(e) (crl_gemm_bf16 colscale on the q columns of the projection).  The forward then runs the
  * seeded / lazy-maximum kernel (base-2 logits straight from the Q.K^T MFMAs; `scale` unused); the backward needs the same flag AND the
  * true `scale` (it stores dQ as the gradient of the unscaled projection output, as without prescaling).  lse is the natural-log
- * log-sum-exp of the true scores either way. */
+ * log-sum-exp of the true scores either way -- with ONE documented deviation: the hand-placed forward stream (non-causal, prescaled q, Nk >= 128:
+ * every training attention of the ViT encoders and the cross-attentions) takes l as the sum of the bf16-ROUNDED probabilities, the operand of
+ * P.V (row sums on the matrix pipe), so that the output's weights sum to one exactly; its lse therefore differs from the fp32 log-sum-exp by at
+ * most log(1 + 2^-8) = 3.9e-3 (rows that one key dominates; random rows: ~1e-4), and the probabilities the backward rebuilds as exp2(s - lse)
+ * sum to 1 within that factor instead of within fp32 rounding.  Bounded by tests (test_attention_fwd_one_wave_per_simd: 5e-3;
+ * test_attention_stream_lse_on_peaked_rows); crl_attn_fwd_set_mode(1) selects the kernels with the fp32 row sum. */
 /* delta: scratch of 2*B*H*Nq fp32 (row constants -delta = -rowsum(dO o O) and -lse/scale that seed the MFMA accumulators).
  * dq/dk/dv strides as q/k/v.  Two forms (same results up to bf16 rounding of dq; both deterministic, no float atomics):
  *   two-pass    dQ pass (recomputes S, dP; produces the row constants) then dK/dV pass (recomputes S, dP): 7 MFMA products per tile;

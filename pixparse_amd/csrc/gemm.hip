@@ -361,10 +361,7 @@ static int64_t quant_rows(int layout, int epilogue, int64_t M, int64_t N, int64_
     if (r < 1 || rem <= 0) continue;
     const int ns = rem_split(epilogue, rem, N, K, 8);
     const int64_t t128 = ((rem + 127) / 128) * ((N + 127) / 128) * ns, full = t128 / (2 * ncu), part = t128 - full * 2 * ncu;
-#ifndef G_QUANT_LAUNCH_US
-#define G_QUANT_LAUNCH_US 14.0     // modelled fixed cost of the second (remainder) launch (A/B knob)
-#endif
-    const double small = G_QUANT_LAUNCH_US + (ns > 1 ? 8.0 : 0.0) + round_us((double)K / ns) * (0.75 * (double)full + (part == 0 ? 0.0 : part <= ncu ? 0.5 : 0.75));
+    const double small = 14.0 + (ns > 1 ? 8.0 : 0.0) + round_us((double)K / ns) * (0.75 * (double)full + (part == 0 ? 0.0 : part <= ncu ? 0.5 : 0.75));
     const double cost = (double)((r * ntn + ncu - 1) / ncu) * round_us((double)K) + (double)g_quant_cost * small;
     if (cost < best_cost - 3.0) { best_cost = cost; best_r = r; }
   }
@@ -382,16 +379,12 @@ static int rem_split(int epilogue, int64_t rem, int64_t N, int64_t K, int cap) {
   // fp32 output) ran 0.4 ms on 24 CUs
   if (!G_REM_SPLIT || !slab_epilogue(epilogue) || (K % 64) != 0) return 1;
   const int64_t nk = K / 64, tiles = ((rem + 127) / 128) * ((N + 127) / 128);
-#ifndef G_REM_SPLIT_MIN_NK
-#define G_REM_SPLIT_MIN_NK 32      // contraction (in K tiles) from which the remainder launch is cut into slabs; 16 = also the K = 1024 launches (A/B knob)
-#endif
-#ifndef G_REM_SPLIT_MIN_CHUNK
-#define G_REM_SPLIT_MIN_CHUNK 8
-#endif
-  if (nk < G_REM_SPLIT_MIN_NK || tiles >= 128) return 1;
+  // (round 6: the K = 1024 launches too -- nk >= 16, slabs of >= 2 K tiles, a cheaper modelled launch -- cut proj + residual 160 -> 155 us and dgrad proj
+  // 121 -> 115 us and left the step where it was: profiles/r6_gemm_rem_split_k1024.txt.  Not taken.)
+  if (nk < 32 || tiles >= 128) return 1;
   int ns = (int)(384 / tiles);
   if (ns > cap) ns = cap;
-  while (ns > 1 && nk / ns < G_REM_SPLIT_MIN_CHUNK) --ns;
+  while (ns > 1 && nk / ns < 8) --ns;
   return ns;
 }
 // The same treatment for a WHOLE forward / dgrad GEMM with few output tiles and a very long contraction -- the LM-head dgrad of a small

@@ -130,6 +130,41 @@ def test_attention_fwd_one_wave_per_simd(dev, B, H, Nq, Nk):
     close(res[0][0], ref, 2e-2, 2e-2, 'stream out')
 
 
+def test_attention_stream_lse_on_peaked_rows(dev):
+    """the forward stream's lse is the log of the sum of the bf16-ROUNDED probabilities.  Worst case = rows that one key dominates (the
+    dominant probability is rounded by up to half a bf16 ulp and nothing averages it out): the probabilities the backward rebuilds from that lse,
+    P = exp(z - lse), must still sum to one within 2^-8 (+ slack), on every row; rows with flat scores sit within 1e-3; and the compiler-scheduled
+    kernel (mode 1: fp32 row sums) stays within fp32 rounding on the same data -- the documented bound of include/crl.h"""
+    from pixparse_amd import hip, ops
+    B, H, Nq, Nk = 1, 2, 512, 1024
+    D, c = H * 64, 0.125 * ops.LOG2E
+    g = torch.Generator(device=dev).manual_seed(17)
+    k = torch.randn(B, Nk, D, generator=g, device=dev)
+    q = torch.randn(B, Nq, D, generator=g, device=dev)
+    # rows 0..255: query i = 9 x (key i): that key's score exceeds the others' by ~ 9 |k|^2 / 8 ~ 70 nats -> one probability ~ 1, the rest ~ 0
+    # rows 256..383: two keys share the row (two rounded probabilities near 0.5);  rows 384..: random (flat) scores
+    q[:, :256] = 9.0 * k[:, :256]
+    q[:, 256:384] = 2.0 * (k[:, 256:384] + k[:, 600:728])
+    qpre, kb = (q * c).to(BF16), k.to(BF16)
+    v = torch.randn(B, Nk, D, generator=g, device=dev).to(BF16)
+    hd = lambda t: t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    z = hd(qpre) @ hd(kb).transpose(-1, -2) * math.log(2.0)
+    worst = {}
+    for mode in (0, 1):
+        hip.call('crl_attn_fwd_set_mode', mode)
+        try:
+            o, lse = torch.empty_like(qpre), torch.empty(B, H, Nq, device=dev)
+            ops.attn_fwd(qpre, kb, v, o, lse, H, 0.125, False, q_prescaled=True)
+        finally:
+            hip.call('crl_attn_fwd_set_mode', 0)
+        assert torch.isfinite(lse).all() and torch.isfinite(o.float()).all()
+        dev_sum = (torch.exp(z - lse[..., None]).sum(-1) - 1.0).abs()          # |sum_k P_bwd - 1| per row
+        worst[mode] = (float(dev_sum[:, :, :384].max()), float(dev_sum[:, :, 384:].max()))
+    assert worst[0][0] < 2.0 ** -8 + 5e-4, worst        # peaked rows: half a bf16 ulp of the dominant probability
+    assert worst[0][1] < 1e-3, worst                    # flat rows: the roundings average out
+    assert worst[1][0] < 1e-3 and worst[1][1] < 1e-3, worst      # fp32 row sums: fp32 rounding of scores up to ~100 nats
+
+
 def test_attention_fwd_persistent_launch_pulls_the_same_blocks(dev):
     """crl_attn_fwd_set_persistent: with more query blocks than workgroup slots (all but 32 CUs reserved: 64 slots) the stream is launched persistently and
     pulls its blocks from the per-XCD ticket lists -- bit-identical to one workgroup per block, also with the static walk and in the one-per-CU form;
