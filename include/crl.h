@@ -88,6 +88,11 @@ int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int64_t K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   const float* bias, void* C, int64_t ldc, void* aux, int64_t ldaux,
                   const float* resid, int64_t ldr, float colscale, int64_t colscale_cols, void* ws, size_t ws_bytes, void* stream);
+/* CRL_TN (weight gradient C[M, N] (+)= A[K, M]^T B[K, N]) with aux != NULL (round 6): aux is float[M] and receives the COLUMN SUMS of A,
+ * aux[m] (+)= sum_k A[k][m] (ldaux != 0: accumulate) -- the bias gradient of the Linear whose weight gradient this is (ref: autograd of
+ * F.linear: grad_bias = grad_output.sum(0)) from the kernel that streams dY anyway: the 4-wave kernel multiplies its A fragments with a fragment
+ * of ones on the matrix pipe (exact fp32 sums of the bf16 values, deterministic order); when another kernel serves the launch the stand-alone
+ * column-sum pass (crl_colsum_bf16) runs inside the call.  Needs ws >= crl_gemm_ws_bytes(CRL_TN, ...).  fp32 epilogues only. */
 /* colscale / colscale_cols (CRL_EPI_BF16 only; 0 columns = off): C[:, 0:colscale_cols] = bf16((v + b) * colscale) -- ONE rounding.  Lets
  * the q part of a q|k|v projection leave the GEMM as q * softmax_scale * log2(e), which is what crl_attn_fwd / crl_attn_bwd take
  * with q_prescaled = 1 (timm Attention: q * self.scale; SDPA: the scale argument): the flash kernels then get base-2 logits straight

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcruller_hip.so')
 SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm4w.hip', 'attention.hip', 'rowops.hip', 'loss_optim.hip', 'swin.hip', 'preprocess.hip', 'skinny.hip', 'attn_decode.hip', 'dropout.hip', 'debug.hip', 'capi.cpp']
-HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", "attn_bwd_sp_body.inc", "attn_fwd4w_body.inc", "attn_fwd2x_body.inc", "gemm4w_body_nt.inc", "gemm4w_body_nn.inc", "gemm4w_body_tn.inc", "gemm4w_body_nt_ovl.inc", "gemm4w_body_nn_ovl.inc", "gemm4w_drain_ovl.inc", os.path.join('..', '..', 'include', 'crl.h')]
+HEADERS = ["common.h", "gemm_common.h", "gemm_epilogue.h", "attn_frag.h", "attn_bwd_sp_body.inc", "attn_fwd4w_body.inc", "attn_fwd2x_body.inc", "gemm4w_body_nt.inc", "gemm4w_body_nn.inc", "gemm4w_body_tn.inc", "gemm4w_body_tn_cs.inc", "gemm4w_body_nt_ovl.inc", "gemm4w_body_nn_ovl.inc", "gemm4w_drain_ovl.inc", os.path.join('..', '..', 'include', 'crl.h')]
 # generated sources: (generator script, output) -- the output is committed; it is regenerated when the script is newer
 GENERATED = [('gen_attn_bwd_sp.py', 'attn_bwd_sp_body.inc'), ('gen_attn_fwd4w.py', 'attn_fwd4w_body.inc'), ('gen_gemm4w.py', 'gemm4w_body_nt.inc')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']

@@ -289,13 +289,16 @@ static int g_policy = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force a 256x2
 #define G_BIG_4W 2
 #endif
 static int g_big4w = G_BIG_4W;
+static bool big_is_4w(int layout, int epi, const gemmc::GemmArgs& a, int nsplit);
 static int big_launch(int layout, int epi, const gemmc::GemmArgs& a, int nsplit, hipStream_t s) {
+  return big_is_4w(layout, epi, a, nsplit) ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
+}
+static bool big_is_4w(int layout, int epi, const gemmc::GemmArgs& a, int nsplit) {
   const bool store_only = epi == CRL_EPI_BF16 || epi == CRL_EPI_F32 || epi == CRL_EPI_F32_ACC;
   const int nk_wg = nsplit > 1 ? a.kchunk : (a.K + 63) / 64;
   // round 6: the dGELU epilogue only multiplies by the derivative the forward saved, so a lone wave per SIMD no longer loses behind it: 417 us against
   // 433 for the 8-wave kernel at the fc2-dgrad shape, equal at the decoder's (profiles/r6_gemm4w_overlapped_dgelu.txt)
-  const bool four = g_big4w == 1 || (g_big4w == 2 && ((store_only && nk_wg >= 32) || epi == CRL_EPI_BF16_DGELU || crl_gemm4w_overlaps(layout, epi, a, nsplit)));
-  return four ? crl_gemm4w_launch(layout, epi, a, nsplit, s) : crl_gemm256_launch(layout, epi, a, nsplit, s);
+  return g_big4w == 1 || (g_big4w == 2 && ((store_only && nk_wg >= 32) || epi == CRL_EPI_BF16_DGELU || crl_gemm4w_overlaps(layout, epi, a, nsplit)));
 }
 extern "C" int crl_gemm_set_big_kernel(int which) {
   if (which < 0 || which > 2) { crl_set_error("crl_gemm_set_big_kernel: 0 = gemm256 (8 waves), 1 = gemm4w (4 waves), 2 = per launch"); return -1; }
@@ -485,8 +488,28 @@ extern "C" int crl_gemm_set_policy(int policy) {
   return 0;
 }
 
+// Bias gradient with the weight gradient (CRL_TN with aux != NULL): partial column sums of A behind the split-K slabs -- up to 16 splits x 4 column
+// tiles x 2 waves rows of M floats from the 4-wave kernel (gen_gemm4w.py colsum_block), or the 64 rows of the stand-alone column-sum kernel when
+// another kernel serves the launch
+static constexpr size_t CS_ROWS = 128;
+static size_t tn_slab_bytes(const Plan& p, int64_t M, int64_t N) { return p.nsplit > 1 ? (((size_t)p.nsplit * M * N * sizeof(float) + 255) & ~(size_t)255) : 0; }
+extern "C" int crl_colsum_bf16(const void* X, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, void* stream);
+namespace {
+__global__ void cs_reduce_kernel(const float* __restrict__ ws, int P, int M, float* __restrict__ out, int acc) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fixed order: deterministic
+  int p = 0;
+  for (; p + 4 <= P; p += 4) { s0 += ws[(size_t)p * M + m]; s1 += ws[(size_t)(p + 1) * M + m]; s2 += ws[(size_t)(p + 2) * M + m]; s3 += ws[(size_t)(p + 3) * M + m]; }
+  for (; p < P; ++p) s0 += ws[(size_t)p * M + m];
+  const float t = (s0 + s1) + (s2 + s3);
+  out[m] = acc ? out[m] + t : t;
+}
+}  // namespace
+
 extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
   const Plan p = plan_gemm(layout, epilogue, M, N, K, true);
+  if (layout == CRL_TN) return tn_slab_bytes(p, M, N) + CS_ROWS * (size_t)M * sizeof(float);
   if (p.nsplit > 1) return (size_t)p.nsplit * M * N * sizeof(float);
   if (!p.big && g_policy == 0) {
     const int ns = few_tiles_split(layout, epilogue, M, N, K);
@@ -543,15 +566,43 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc; a.ldaux = (int)ldaux; a.ldr = (int)ldr;
   a.a_bytes = (uint32_t)ab; a.b_bytes = (uint32_t)bb;
   a.sched = nullptr;
+  a.cs_ws = nullptr; a.cs_ntn = 0;
   a.colscale = colscale; a.colscale_cols = (int)colscale_cols;
   a.ntm = (int)((M + BM - 1) / BM); a.ntn = (int)((N + BN - 1) / BN);
   hipStream_t s = as_stream(stream);
   Plan p = plan_gemm(layout, epilogue, M, N, K, ws != nullptr);
   if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * M * N * sizeof(float)) p = plan_gemm(layout, epilogue, M, N, K, false);
+  // CRL_TN with aux: aux[m] (+)= sum_k A[k][m], the bias gradient of the Linear whose weight gradient this is (ldaux != 0: accumulate)
+  float* const cs_out = layout == CRL_TN ? (float*)aux : nullptr;
+  float* cs_part = nullptr;
+  if (cs_out) {
+    CRL_CHECK(epilogue == CRL_EPI_F32 || epilogue == CRL_EPI_F32_ACC, "crl_gemm_bf16: the column sums ride the fp32 weight-gradient epilogues only");
+    const size_t off = tn_slab_bytes(p, M, N);
+    CRL_CHECK(ws && ws_bytes >= off + CS_ROWS * (size_t)M * sizeof(float), "crl_gemm_bf16: the column sums need crl_gemm_ws_bytes() of scratch");
+    cs_part = (float*)((char*)ws + off);
+  }
+  // after the GEMM: the partial rows the 4-wave kernel wrote -> aux; any other kernel: the stand-alone column-sum pass over A
+  auto finish_colsum = [&](bool fused, int nsplit_run) -> int {
+    if (!cs_out) return 0;
+    if (!fused) return crl_colsum_bf16(A, K, M, lda, cs_out, ldaux != 0, cs_part, stream);
+    cs_reduce_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(cs_part, nsplit_run * a.cs_ntn * 2, (int)M, cs_out, ldaux != 0);
+    CRL_LAUNCH_CHECK("crl_gemm_bf16(column-sum reduce)");
+    return 0;
+  };
   if (bk == 32) { p.big = false; p.nsplit = 1; p.chunk = (K + 31) / 32; }
   a.kchunk = (int)p.chunk;
   a.slab_stride = 0;
   if (p.big) { a.ntm = (int)((M + 255) / 256); a.ntn = (int)((N + 255) / 256); }
+  bool cs_fused = false;
+  if (cs_out && p.big) {
+    GemmArgs probe = a;
+    if (p.nsplit > 1) probe.kchunk = (int)p.chunk;
+    if (big_is_4w(CRL_TN, p.nsplit > 1 ? CRL_EPI_F32 : epilogue, probe, p.nsplit)) {
+      cs_fused = true;
+      a.cs_ws = cs_part;
+      a.cs_ntn = a.ntn >= 4 ? 4 : a.ntn >= 2 ? 2 : 1;
+    }
+  }
   if (p.nsplit > 1) {
     GemmArgs b = a;
     b.C = ws; b.ldc = (int)N; b.slab_stride = (size_t)M * N;
@@ -560,7 +611,11 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc,
                                                                     epilogue == CRL_EPI_F32_ACC);
     CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk reduce)");
-    return 0;
+    return finish_colsum(cs_fused, p.nsplit);
+  }
+  if (cs_out) {      // weight gradient without a contraction split: one launch (never row-cut: quant_rows leaves CRL_TN alone), then the column sums
+    if (int rc = p.big ? big_launch(layout, epilogue, a, 1, s) : launch_epi<CRL_TN>(a, epilogue, bk, 1, s)) return rc;
+    return finish_colsum(cs_fused, 1);
   }
   // slabs of a cut contraction -> C with the epilogue applied (plain fp32 store / accumulate, or bias + bf16 / bias + residual)
   auto reduce_slabs = [&](const GemmArgs& full, int nsl, const char* what) -> int {

@@ -301,7 +301,24 @@ __global__ __launch_bounds__(T4W, 1) void gemm4w_kernel(const GemmArgs g) {
                arAt4 = unitA + tr_addr(4), arAt5 = unitA + tr_addr(5), arAt6 = unitA + tr_addr(6), arAt7 = unitA + tr_addr(7);
       uint32_t arBt0 = unitB + tr_addr(0), arBt1 = unitB + tr_addr(1), arBt2 = unitB + tr_addr(2), arBt3 = unitB + tr_addr(3),
                arBt4 = unitB + tr_addr(4), arBt5 = unitB + tr_addr(5), arBt6 = unitB + tr_addr(6), arBt7 = unitB + tr_addr(7);
+      const int tn_cur = n0 >> 8;
+      if (g.cs_ws != nullptr && tn_cur < g.cs_ntn) {
+        // the bias gradient rides the weight gradient: column sums of this wave's A half on the matrix pipe, on every (2 cs_ntn)-th K tile -- phase
+        // 2 tn + wc, so that the waves / workgroups reading the same A panel cover the contraction between them (gen_gemm4w.py colsum_block)
+        f32x4 cs[8];
+        const uint32_t s_csmask = (uint32_t)(2 * g.cs_ntn - 1);
+        uint32_t s_csk = ((uint32_t)(2 * tn_cur + wc) - (uint32_t)kt0) & s_csmask, s_csgo;
+#include "gemm4w_body_tn_cs.inc"
+        (void)s_csgo;
+        if (lq == 0) {      // lane li holds the sum of row 16 i + li of the wave's A half (the same value in all four registers and all four lq groups)
+          float* dst = g.cs_ws + ((size_t)((blockIdx.y * g.cs_ntn + tn_cur) * 2 + wc)) * (size_t)g.M + (size_t)(m0 + 128 * wr + li);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (m0 + 128 * wr + 16 * i + li < g.M) dst[16 * i] = cs[i][0];
+        }
+      } else {
 #include "gemm4w_body_tn.inc"
+      }
     }
     // ---- next tile (the stream ends behind a barrier: the ring is idle): thread 0 publishes it through the first word of the LDS
     int next_logical = logical + (int)gridDim.x;

@@ -17,6 +17,10 @@ struct GemmArgs {
   uint32_t* sched;       // dynamic tile scheduler state of this launch (persistent launches only, else nullptr): see TileSched
   float colscale;        // bf16 epilogue: output columns [0, colscale_cols) are multiplied by colscale before the rounding (0 columns = off);
   int colscale_cols;     // the q part of a fused q|k|v projection leaves the GEMM as q * scale * log2(e) (crl_attn_* with q_prescaled)
+  // weight-gradient layout, 4-wave kernel only (gemm4w.hip, gen_gemm4w.py colsum_block): the column sums of the A operand (= the bias gradient) as
+  // partial rows cs_ws[((split * cs_ntn + tn) * 2 + wc) * M + m]; the first cs_ntn (1, 2 or 4) column tiles of a row of tiles share the work
+  float* cs_ws;
+  int cs_ntn;
 };
 
 // ---- dynamic tile scheduler of the persistent kernels -------------------------------------------------------------------------

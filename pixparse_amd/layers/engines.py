@@ -94,9 +94,8 @@ class _Base:
     def lin_wgrad(self, name, dy, x, has_bias=True, n=None, k=None):
         gw = self.G(name + '.weight')
         gw2 = gw.view(gw.shape[0], -1)
-        ops.linear_wgrad(dy, x, gw2, True, n=n, k=k)
-        if has_bias:
-            ops.colsum(dy, self.G(name + '.bias'), True, n=n)
+        # the bias gradient (column sums of dy) rides the weight-gradient GEMM, which streams dy anyway
+        ops.linear_wgrad(dy, x, gw2, True, n=n, k=k, dbias=self.G(name + '.bias') if has_bias else None)
 
 
 # ============================================================================================ ViT
@@ -792,8 +791,7 @@ class BartEngine(_Base):
             # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
             if not fused_kv:
                 ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32 if i == self.L - 1 else EPI_F32_ACC)
-            ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True)
-            ops.colsum(dkv2, self.fb('g', lp, 'encoder_attn', 'k_proj', 2), True)
+            ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True, dbias=self.fb('g', lp, 'encoder_attn', 'k_proj', 2))
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
             self._branch_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, dtb, lp + 'self_attn.out_proj', 1 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'self_attn.out_proj.weight'), do)
@@ -802,8 +800,7 @@ class BartEngine(_Base):
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
                          dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True, drop=drop, site=200 + 2 * i, q_prescaled=True)
             ops.linear_dgrad(dqkv, self.fw('w', lp, 'self_attn', 'q_proj', 3), dyb)
-            ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True)
-            ops.colsum(dqkv, self.fb('g', lp, 'self_attn', 'q_proj', 3), True)
+            ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True, dbias=self.fb('g', lp, 'self_attn', 'q_proj', 3))
             dy32 = dt  # residual-path gradient for the layer below (dt now holds d t1)
             if on_layer_done:
                 on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')

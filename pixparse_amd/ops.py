@@ -9,6 +9,7 @@ from . import hip
 from .hip import NT, NN, TN, EPI_BF16, EPI_BF16_GELU, EPI_BF16_DGELU, EPI_F32_RESID, EPI_F32, EPI_F32_ACC  # noqa: F401
 
 BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+_FUSE_DBIAS = __import__('os').environ.get('PIXPARSE_AMD_FUSE_DBIAS', '1') != '0'     # A/B switch: bias gradients from the weight-gradient GEMM (default) or a pass of their own
 VOCAB_PAD = 128   # logits row stride / embedding rows are padded to a multiple of this
 K_PAD = 64        # contraction dims of NT/NN GEMMs are padded to a multiple of this when needed
 
@@ -132,12 +133,21 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epi: int 
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool = True,
-                 n: Optional[int] = None, k: Optional[int] = None) -> None:
-    """dw[N, Kin] (+)= dy[M, N]^T @ x[M, Kin]  (fp32 output straight into the grad arena)."""
+                 n: Optional[int] = None, k: Optional[int] = None, dbias: Optional[torch.Tensor] = None, dbias_accumulate: bool = True) -> None:
+    """dw[N, Kin] (+)= dy[M, N]^T @ x[M, Kin]  (fp32 output straight into the grad arena).
+    dbias (optional, fp32 [N]): the bias gradient dbias[n] (+)= sum_m dy[m, n] from the SAME call -- the 4-wave weight-gradient kernel sums the
+    columns of its A operand on the matrix pipe while it streams them (crl_gemm_bf16, CRL_TN with aux); any other kernel: the column-sum pass."""
     M = dy.shape[0]
     N = n if n is not None else dy.shape[1]
     Kin = k if k is not None else x.shape[1]
-    gemm(TN, EPI_F32_ACC if accumulate else EPI_F32, N, Kin, M, dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0))
+    if dbias is not None:
+        _chk(dbias, F32, 'linear_wgrad dbias')
+        if not _FUSE_DBIAS:       # A/B switch (PIXPARSE_AMD_FUSE_DBIAS=0): the separate column-sum pass of rounds 1-5
+            gemm(TN, EPI_F32_ACC if accumulate else EPI_F32, N, Kin, M, dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0))
+            colsum(dy, dbias, dbias_accumulate, n=n)
+            return
+    gemm(TN, EPI_F32_ACC if accumulate else EPI_F32, N, Kin, M, dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0),
+         aux=dbias, ldaux=1 if (dbias is not None and dbias_accumulate) else 0)
 
 
 class Scratch:

@@ -232,6 +232,14 @@ def test_wgrad_full_contraction_sampled_rows_and_linearity(dev):
     bias = torch.zeros(N, device=dev)
     ops.colsum(dy, bias, accumulate=False)
     _close(bias, dy.float().sum(0), 2e-3, 2e-3 * float(dy.float().sum(0).abs().max()), 'bias grad colsum')
+    # ... and the form the step uses since round 6: the bias gradient from the weight-gradient call itself (column sums on the matrix pipe)
+    dw2 = torch.zeros(N, K, device=dev)
+    bias2 = torch.full((N,), float('nan'), device=dev)
+    ops.linear_wgrad(dy, x, dw2, accumulate=False, dbias=bias2, dbias_accumulate=False)
+    assert torch.equal(dw2, first), 'the weight gradient changed with the column sums on'
+    ref64 = dy.double().sum(0)
+    assert float((bias2.double() - ref64).abs().max()) < 2e-5 * float(dy.float().abs().sum(0).max()) + 1e-4
+    assert float((bias2 - bias).abs().max()) < 2e-5 * float(dy.float().abs().sum(0).max()) + 1e-4      # same sums, another order
 
 
 def test_layernorm_and_cross_entropy_full_size(dev):

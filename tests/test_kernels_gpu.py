@@ -962,6 +962,44 @@ def test_gemm_quarter_full_chip_long_contraction_split(dev):
     assert torch.equal(o32, o32b), 'slab reduction must be deterministic'
 
 
+@pytest.mark.parametrize('Mrows,N,K', [(5000, 1024, 1024), (49512 // 4, 1024, 512), (6000, 520, 448), (300, 264, 192), (4000, 2048, 256), (70000, 256, 256)])
+def test_wgrad_with_bias_gradient(dev, Mrows, N, K):
+    """linear_wgrad(..., dbias=...): the bias gradient (column sums of dy) from the weight-gradient call.  The 4-wave kernel sums the columns of its A
+    operand on the matrix pipe (eight MFMAs against a fragment of ones on the K tiles a wave is on duty for; the two waves and the <= 4 column
+    tiles that read the same A panel share the contraction) -- exact fp32 sums of the bf16 values like the stand-alone pass, in another order;
+    every other kernel choice falls back to that pass inside the same entry point.  Against fp64 torch; accumulate and overwrite; twice the same
+    bits; the weight gradient itself bit-identical to the call without dbias; ragged contraction (rows not a multiple of 64) and ragged N"""
+    from pixparse_amd import hip, ops
+    dy = rnd((Mrows, N), dev, 1.0, 1, BF16)
+    x = rnd((Mrows, K), dev, 1.0, 2, BF16)
+    ref = dy.double().sum(0)
+    tol = 2e-5 * float(dy.float().abs().sum(0).max()) + 1e-4
+    for big in (2, 1, 0):                      # per launch (product), the 4-wave kernel, the 8-wave kernel (stand-alone pass inside)
+        hip.call('crl_gemm_set_big_kernel', big)
+        try:
+            dw0 = torch.zeros(N, K, device=dev)
+            ops.linear_wgrad(dy, x, dw0, accumulate=False)
+            dw = torch.zeros(N, K, device=dev)
+            db = torch.full((N,), float('nan'), device=dev)
+            ops.linear_wgrad(dy, x, dw, accumulate=False, dbias=db, dbias_accumulate=False)
+            assert torch.equal(dw, dw0), f'big={big}: the weight gradient changed with the column sums on'
+            assert float((db.double() - ref).abs().max()) < tol, (big, float((db.double() - ref).abs().max()), tol)
+            db2 = torch.full((N,), 3.0, device=dev)
+            ops.linear_wgrad(dy, x, dw, accumulate=True, dbias=db2, dbias_accumulate=True)
+            assert float((db2.double() - 3.0 - ref).abs().max()) < tol
+            db3 = torch.empty(N, device=dev)
+            ops.linear_wgrad(dy, x, dw, accumulate=False, dbias=db3, dbias_accumulate=False)
+            assert torch.equal(db3, db), f'big={big}: not reproducible'
+        finally:
+            hip.call('crl_gemm_set_big_kernel', 2)
+    # a column-restricted call (n < dy.shape[1]: padded projections) sums only those columns
+    if N >= 512:
+        db = torch.empty(N - 256, device=dev)
+        dw = torch.zeros(N - 256, K, device=dev)
+        ops.linear_wgrad(dy, x, dw, accumulate=False, n=N - 256, dbias=db, dbias_accumulate=False)
+        assert float((db.double() - ref[:N - 256]).abs().max()) < tol
+
+
 def test_gemm_256_splitk_wgrad(dev):
     from pixparse_amd import hip, ops
     Mrows, N, K = 5000, 520, 448                # contraction over 5000 rows -> 79 K tiles, split into slabs
