@@ -1186,6 +1186,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_kernel(const AttnArgs a, u
 // hazard rules are documented there).  This wrapper computes the per-lane LDS / global offsets and the scalar state, stages K and the
 // first two query tiles, and hands everything to the generated asm statement, which owns v[0:223] and a[0:255].  q must be prescaled
 // (base-2 logits straight from the MFMAs: no multiply per element).
+#ifndef SPX_FIRST_VARIANT
+#define SPX_FIRST_VARIANT 1      // 0: every block through the general form (a descriptor without records feeds zeros to the first block of a chain: rounds 4 / 5)
+#endif
 constexpr int SPX_SLOT = 16384 + 1024;
 constexpr int SPX_DS = 65536;
 constexpr int SPX_PART = SPX_DS + 2 * 32768;       // running partial dQ tiles: ring of 3 buffers x 4 waves x 2 KiB
@@ -1275,7 +1278,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
 
   const int kb_end = min(a.nkt, (cidx + 1) * chain);
   for (int kblk = cidx * chain; kblk < kb_end; ++kblk) {
-    // the first key block of a chain starts from zero: a descriptor without records returns zeros
+    // the first key block of a chain starts from zero (its own stream variant; with SPX_FIRST_VARIANT = 0: a descriptor without records returns zeros)
     const u32x4 rprev = make_srd(slab, kblk == cidx * chain ? 0u : (uint32_t)((int64_t)nq * HD2));
     // every per-lane value is derived afresh from an OPAQUE copy of the thread index: hoisted out of the key-block loop it would have to
     // live across the stream, which leaves the compiler 32 vector registers (26 of them its operands) -- i.e. in scratch memory
@@ -1318,10 +1321,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
       stage64(rdo, base + 8192, sdo, t * 64, a.do_rs, wave);
       dma4(rrc, base + 16384 + wave * 256, rcv, (uint32_t)t * 256u);
     }
+    const bool first_of_chain = kblk == cidx * chain;      // its running partial is zero: the stream variant without the running-tile machinery
+    if (!(SPX_FIRST_VARIANT && first_of_chain)) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      dma16(rprev, s_m0p + t * 8192u, slabv, (uint32_t)t * s_slabstep);
-      dma16(rprev, s_m0p + t * 8192u + 1024u, slabv, (uint32_t)t * s_slabstep + 32u);
+      for (int t = 0; t < 2; ++t) {
+        dma16(rprev, s_m0p + t * 8192u, slabv, (uint32_t)t * s_slabstep);
+        dma16(rprev, s_m0p + t * 8192u + 1024u, slabv, (uint32_t)t * s_slabstep + 32u);
+      }
     }
 #ifdef SPX_STAMPS
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -1335,6 +1341,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_spx_kernel(const AttnArgs a, 
     unsigned long long* const dbg4 = spx_trace + (4 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
     unsigned long long* const dbg5 = spx_trace + (5 * (SPX_TR_WG + 1) + trw) * SPX_TR_PASSES;
 #endif
+    // ONE statement holding both variants of the stream (general | first key block of a chain, selected by s_first): see gen_attn_bwd_sp.py FIRST
+    const uint32_t s_first = (uint32_t)__builtin_amdgcn_readfirstlane((SPX_FIRST_VARIANT && first_of_chain) ? 1 : 0);
 #include "attn_bwd_sp_body.inc"
 #ifdef SPX_STAMPS
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();

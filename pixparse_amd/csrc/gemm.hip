@@ -145,8 +145,24 @@ __device__ __forceinline__ float4 nt_load_f4(const float* p) {
   const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
   return float4{v[0], v[1], v[2], v[3]};
 }
+// (round 6) the blocks behind the first `nb_slabs` reduce the partial column sums the 4-wave weight-gradient kernel left behind the slabs (bias gradient,
+// crl_gemm_bf16 CRL_TN with aux): one launch for both reductions instead of two
+__device__ __forceinline__ void cs_reduce_body(const float* __restrict__ ws, int P, int M, float* __restrict__ out, int acc, int m) {
+  if (m >= M) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fixed order: deterministic
+  int p = 0;
+  for (; p + 4 <= P; p += 4) { s0 += ws[(size_t)p * M + m]; s1 += ws[(size_t)(p + 1) * M + m]; s2 += ws[(size_t)(p + 2) * M + m]; s3 += ws[(size_t)(p + 3) * M + m]; }
+  for (; p < P; ++p) s0 += ws[(size_t)p * M + m];
+  const float t = (s0 + s1) + (s2 + s3);
+  out[m] = acc ? out[m] + t : t;
+}
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t slab, float* __restrict__ out, int M, int N,
-                                     int ldc, int acc) {
+                                     int ldc, int acc, unsigned nb_slabs = 0xffffffffu, const float* __restrict__ cs_ws = nullptr, int cs_P = 0,
+                                     float* __restrict__ cs_out = nullptr, int cs_acc = 0) {
+  if (blockIdx.x >= nb_slabs) {
+    cs_reduce_body(cs_ws, cs_P, M, cs_out, cs_acc, (int)((blockIdx.x - nb_slabs) * blockDim.x + threadIdx.x));
+    return;
+  }
   const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (idx >= (size_t)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx % N);
@@ -496,14 +512,7 @@ static size_t tn_slab_bytes(const Plan& p, int64_t M, int64_t N) { return p.nspl
 extern "C" int crl_colsum_bf16(const void* X, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, void* stream);
 namespace {
 __global__ void cs_reduce_kernel(const float* __restrict__ ws, int P, int M, float* __restrict__ out, int acc) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fixed order: deterministic
-  int p = 0;
-  for (; p + 4 <= P; p += 4) { s0 += ws[(size_t)p * M + m]; s1 += ws[(size_t)(p + 1) * M + m]; s2 += ws[(size_t)(p + 2) * M + m]; s3 += ws[(size_t)(p + 3) * M + m]; }
-  for (; p < P; ++p) s0 += ws[(size_t)p * M + m];
-  const float t = (s0 + s1) + (s2 + s3);
-  out[m] = acc ? out[m] + t : t;
+  cs_reduce_body(ws, P, M, out, acc, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 }  // namespace
 
@@ -608,10 +617,16 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     b.C = ws; b.ldc = (int)N; b.slab_stride = (size_t)M * N;
     if (int rc = p.big ? big_launch(CRL_TN, CRL_EPI_F32, b, p.nsplit, s) : launch_epi<CRL_TN>(b, CRL_EPI_F32, bk, p.nsplit, s)) return rc;
     const size_t n4 = (size_t)M * N / 4;
-    splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc,
-                                                                    epilogue == CRL_EPI_F32_ACC);
+    const unsigned nb = (unsigned)((n4 + 255) / 256);
+    if (cs_fused) {      // the slab reduce and the column-sum reduce in one launch
+      splitk_reduce_kernel<<<nb + (unsigned)((M + 255) / 256), 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc,
+                                                                           epilogue == CRL_EPI_F32_ACC, nb, cs_part, p.nsplit * a.cs_ntn * 2, cs_out, ldaux != 0);
+      CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk + column-sum reduce)");
+      return 0;
+    }
+    splitk_reduce_kernel<<<nb, 256, 0, s>>>((const float*)ws, p.nsplit, (size_t)M * N, (float*)C, (int)M, (int)N, (int)ldc, epilogue == CRL_EPI_F32_ACC);
     CRL_LAUNCH_CHECK("crl_gemm_bf16(splitk reduce)");
-    return finish_colsum(cs_fused, p.nsplit);
+    return finish_colsum(false, p.nsplit);
   }
   if (cs_out) {      // weight gradient without a contraction split: one launch (never row-cut: quant_rows leaves CRL_TN alone), then the column sums
     if (int rc = p.big ? big_launch(layout, epilogue, a, 1, s) : launch_epi<CRL_TN>(a, epilogue, bk, 1, s)) return rc;

@@ -169,7 +169,7 @@ def dq_quarter(w):
     (load_part / unpack_part: zeros for the first key block of a chain)"""
     out = []
     for kk in range(4):
-        c = ('v', V_DQ)
+        c = '0' if (FIRST[0] and w == 0 and kk == 0) else ('v', V_DQ)
         out.append(mfma(('v', V_DQ), ('a', A_KA + 4 * (4 * w + kk)), ('v', V_DSF + 4 * kk), c, 16, 4, 4, 16))
     return out
 
@@ -380,7 +380,8 @@ def build_iteration(p):
     G.spread(g0 + 7, g0 + 16, dma_tile((p + 2) % 3))
     # ---- slot 0: the running partial of tile t - 1 -> C operand of its first dQ MFMA (MFMA 16 of the pass)
     # (its two LDS reads were issued in the last gap of the previous pass -- see below -- and are covered by the rendezvous)
-    G.fill(0, 15, unpack_part())
+    if not FIRST[0]:
+        G.fill(0, 15, unpack_part())
     # ---- slot 3: dQ conversion + stores (dQ MFMAs are 8..11 of the slot), address toggles, ring advance of the transposed addresses
     g0 = 60
     cv, st = dq_store()
@@ -389,8 +390,9 @@ def build_iteration(p):
         G.put(g0 + 19, st[k])
     # the running partial of tile t (DMA'd one pass ago, landed at this pass's rendezvous) for the NEXT pass, into the upper halves of the
     # accumulator block, which the conversions above have just released
-    for ins in load_part(ring_t) + dma_part((p + 2) % 3):
-        G.put(g0 + 19, ins)
+    if not FIRST[0]:
+        for ins in load_part(ring_t) + dma_part((p + 2) % 3):
+            G.put(g0 + 19, ins)
     return bb, G
 
 
@@ -409,6 +411,12 @@ BARRIER_AT = int(OPTS.get('barrier_at', 0))     # number of MFMAs of a pass issu
 STAMPS = 'stamps' in OPTS     # diagnostic build (-DSPX_STAMPS): six s_memtime stamps per pass, written to a trace by scalar stores
 STAMP_AT = {19: 2, 39: 3, 59: 4}  # after MFMA n -> stamp k   (0: after the wait at the top, 1: after the barrier, 5: end of the pass)
 in_loop = [False]
+# FIRST[0]: generate the variant for the FIRST key block of a chain (attn_bwd_sp_body_first.inc, round 6).  Its running partial is zero by
+# definition, so the whole running-tile machinery goes: no read-back (load_part), no unpack (16 VALU per pass), no LDS-DMA of the partial
+# (2 pieces per pass); the tile's first dQ MFMA starts from the inline constant 0 -- the same +0.0 the unpacked zero bits gave, so dQ / dK / dV
+# are bit-identical to the general form fed a descriptor without records (which is what round 4/5 ran for these blocks: +3 % of the stream
+# for nothing on 7 of every 25 key blocks at chain 4).  The rendezvous then leaves 2 operations in flight (the slab stores), not 4.
+FIRST = [False]
 
 
 def drop_class(ins):
@@ -559,7 +567,7 @@ def generate():
         off = (kk >> 2) * 8192 + (kk & 3) * 2048
         E(ds_read_tr('a', A_KA + 4 * kk, 'atrk0', off))
         E(ds_read_tr('a', A_KA + 4 * kk + 2, 'atrk1', off))
-    for ins in load_seeds(0) + load_qf(0) + load_part(2):     # pass 0 accumulates dQ of "tile -1" (dS = 0, stored nowhere): any seed will do
+    for ins in load_seeds(0) + load_qf(0) + ([] if FIRST[0] else load_part(2)):     # pass 0 accumulates dQ of "tile -1" (dS = 0, stored nowhere): any seed will do
         E(ins)
     H.drain('s_waitcnt lgkmcnt(0)')
     if STAMPS:
@@ -586,7 +594,7 @@ def generate():
         # every LDS read of the previous pass are complete.  It sits BEHIND the first BARRIER_AT MFMAs of the pass (S / dP of the next block from
         # operands already in registers; their gaps hold VALU work only), so the wait overlaps matrix work instead of draining the pipe.
         def rendezvous():
-            H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
+            H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)' if FIRST[0] else 's_waitcnt vmcnt(4) lgkmcnt(0)')
             if STAMPS:
                 # the six stamps of the previous pass have arrived (lgkmcnt(0) above): write them out, then stamp this pass
                 H.out.append(I('\n\t'.join(f's_store_dwordx2 %[st{k}], %[dbg{k}], %[s_dbgoff]' for k in range(6)) +
@@ -617,7 +625,7 @@ def generate():
     # spend on a tile of zero rows.  The pass that follows pass p reads the dS buffer of parity p & 1: one copy per parity.
     for par in range(2):
         H.out.append(I(f'DRAIN{par}%=:', 'label'))
-        H.drain('s_waitcnt vmcnt(4) lgkmcnt(0)')
+        H.drain('s_waitcnt vmcnt(2) lgkmcnt(0)' if FIRST[0] else 's_waitcnt vmcnt(4) lgkmcnt(0)')
         E(I('s_barrier', 'barrier'))
         E(salu(f's_add_u32 {op("s_slaboff")}, {op("s_slaboff")}, {op("s_slabstep")}'))
         H.settle_mfma()                       # the S / dP results of the last pass are not read any more
@@ -625,8 +633,9 @@ def generate():
             E(ins)
         for m in m2_block(1):
             E(m)
-        for ins in unpack_part():
-            E(ins)
+        if not FIRST[0]:
+            for ins in unpack_part():
+                E(ins)
         for w in range(4):                    # one quarter of dS^T at a time (the fragment registers are shared); once per workgroup
             if w:
                 for ins in load_dsf(w, par):
@@ -677,16 +686,28 @@ def generate():
     return H.out, G
 
 
-def render(stream):
+def render(stream, first_stream=None):
+    """one asm statement; with first_stream: BOTH variants in it, selected by the scalar operand s_first (1 = first key block of a chain) -- one
+    operand set for the compiler (two statements behind an if / else made hipcc spill 112 bytes per lane around them)"""
     lines = []
+    if first_stream is not None:
+        lines += ['s_cmp_eq_u32 %[s_first], 1', 's_cbranch_scc1 FIRSTV%=']
     for ins in stream:
         for ln in ins.text.split('\n\t'):
             lines.append(ln)
+    if first_stream is not None:
+        lines += ['s_branch BOTHDONE%=', 'FIRSTV%=:']
+        for ins in first_stream:
+            for ln in ins.text.split('\n\t'):
+                for lab in ('LOOP%=', 'DRAIN0%=', 'DRAIN1%=', 'DONE%='):
+                    ln = ln.replace(lab, 'F_' + lab)
+                lines.append(ln)
+        lines += ['BOTHDONE%=:']
     body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
     srw = SRW + (['s_dbgoff'] if STAMPS else [])
     outs = ', '.join(f'[{n}] "+&v"({n})' for n in VOPS) + ',\n      ' + ', '.join(f'[{n}] "+&s"({n})' for n in srw) + ',\n      ' + \
         ', '.join(f'[{n}] "=&s"({n})' for n in STMP + ([f'st{k}' for k in range(6)] if STAMPS else []))
-    ins_ = ', '.join(f'[{n}] "s"({n})' for n in SRDS) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in SIN + ([f'dbg{k}' for k in range(6)] if STAMPS else []))
+    ins_ = ', '.join(f'[{n}] "s"({n})' for n in SRDS) + ',\n      ' + ', '.join(f'[{n}] "s"({n})' for n in SIN + (['s_first'] if first_stream is not None else []) + ([f'dbg{k}' for k in range(6)] if STAMPS else []))
     clob = ', '.join(f'"v{i}"' for i in range(N_HAND)) + ',\n      ' + ', '.join(f'"a{i}"' for i in range(256)) + ', "vcc", "scc", "memory"'
     return ('// GENERATED by gen_attn_bwd_sp.py -- do not edit; see that file for the register map and the schedule\n'
             'asm volatile(\n' + body + '\n    : ' + outs + '\n    : ' + ins_ + '\n    : ' + clob + ');\n')
@@ -701,10 +722,13 @@ def stats(stream, G):
 
 
 if __name__ == '__main__':
-    stream, G = generate()
     here = os.path.dirname(os.path.abspath(__file__))
+    FIRST[0] = True
+    first_stream, _ = generate()
+    FIRST[0] = False
+    stream, G = generate()
     with open(os.path.join(here, 'attn_bwd_sp_body.inc'), 'w') as f:
-        f.write(render(stream))
+        f.write(render(stream, None if 'nofirst' in OPTS else first_stream))
     kinds, costs = stats(stream, G)
     if '-v' in sys.argv:
         print(kinds)

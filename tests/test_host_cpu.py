@@ -182,12 +182,22 @@ def test_attention_backward_stream_is_in_sync_and_its_hazard_pass_bites():
     for k in ('SPX_DROP', 'SPX_OPTS'):
         assert not os.environ.get(k), f'{k} is set: the committed stream is the default build'
     spec.loader.exec_module(gen)
+    # round 6: ONE statement with two variants of the stream -- the general form and the form for the first key block of a chain (no running partial)
+    gen.FIRST[0] = True
+    first_stream, _ = gen.generate()
+    gen.FIRST[0] = False
     stream, _ = gen.generate()
-    text = gen.render(stream)
+    text = gen.render(stream, first_stream)
     assert text == open(os.path.join(b.CSRC, 'attn_bwd_sp_body.inc')).read(), 'attn_bwd_sp_body.inc is stale: run python pixparse_amd/csrc/gen_attn_bwd_sp.py'
-    body = text[text.index('LOOP%=:'):text.index('DRAIN0%=:')]
-    assert body.count('v_mfma_f32_32x32x16_bf16') == 6 * 80 and body.count('s_barrier') == 6          # six unrolled passes, one rendezvous each
-    assert body.count('v_exp_f32') == 6 * 64 and body.count('ds_read_b64_tr_b16') == 6 * 64 and body.count('ds_write_b64') == 6 * 16
+    body = text[text.index('"LOOP%=:'):text.index('"DRAIN0%=:')]
+    fbody = text[text.index('"F_LOOP%=:'):text.index('"F_DRAIN0%=:')]
+    for bd in (body, fbody):
+        assert bd.count('v_mfma_f32_32x32x16_bf16') == 6 * 80 and bd.count('s_barrier') == 6          # six unrolled passes, one rendezvous each
+        assert bd.count('v_exp_f32') == 6 * 64 and bd.count('ds_read_b64_tr_b16') == 6 * 64 and bd.count('ds_write_b64') == 6 * 16
+    # the running-tile machinery per pass: 2 read-backs, 16 unpack operations, 2 LDS-DMA pieces of the partial -- all gone from the first-block variant
+    assert body.count('ds_read2st64_b64') == 6 * 2 and fbody.count('ds_read2st64_b64') == 0
+    assert body.count('%[rprev]') == 6 * 2 and fbody.count('%[rprev]') == 0
+    assert body.count('s_waitcnt vmcnt(4) lgkmcnt(0)') == 6 and fbody.count('s_waitcnt vmcnt(2) lgkmcnt(0)') == 6
     assert not re.search(r'scratch_|v_pk_mul_f32', text)
     # the hazard pass: a VALU read of an accumulator right behind the MFMA that writes it must be refused
     H = gen.Hazards()
