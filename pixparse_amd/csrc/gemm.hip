@@ -428,6 +428,19 @@ static int few_tiles_split(int layout, int epilogue, int64_t M, int64_t N, int64
   return ns;
 }
 
+// Round 6: a forward / dgrad GEMM whose 256x256 tiles fill at most HALF the chip and whose contraction is long (>= 64 K tiles) -- the decoder's 8184-row
+// fc2 and fc1 dgrad (128 tiles x 64 K tiles) and the LM-head dgrad (128 tiles x 786) -- used to run as 512 tiles of the 128x128 kernel at half the
+// rate (the LM-head dgrad: 1.1 ms = 0.76 PF/s).  Now: CUs / tiles contraction slices of >= 32 K tiles on the 4-wave 256x256 kernel (fp32 slabs in the
+// caller's scratch) + the slab reduce that applies the epilogue.  1 = no split.
+static int half_chip_split(int layout, int epilogue, int64_t M, int64_t N, int64_t K) {
+  if (layout == CRL_TN || !slab_epilogue(epilogue) || (K % 64) != 0 || M < 256 || N < 256) return 1;
+  const int64_t nk = K / 64, t256 = ((M + 255) / 256) * ((N + 255) / 256), ncu = crl_gemm_cus();
+  if (nk < 64 || t256 * 2 > ncu || t256 * 8 < ncu) return 1;
+  int ns = (int)(ncu / t256);
+  while (ns > 1 && nk / ns < 32) --ns;
+  return ns;
+}
+
 namespace {
 // bf16 values in (-1, 1) from a hash of the element index: calibration operands (constant data would run at a higher clock than real activations)
 __global__ void calib_fill_kernel(uint32_t* __restrict__ p, size_t n2) {
@@ -521,6 +534,8 @@ extern "C" size_t crl_gemm_ws_bytes(int layout, int epilogue, int64_t M, int64_t
   if (layout == CRL_TN) return tn_slab_bytes(p, M, N) + CS_ROWS * (size_t)M * sizeof(float);
   if (p.nsplit > 1) return (size_t)p.nsplit * M * N * sizeof(float);
   if (!p.big && g_policy == 0) {
+    const int nh = half_chip_split(layout, epilogue, M, N, K);
+    if (nh > 1) return (size_t)nh * M * N * sizeof(float);
     const int ns = few_tiles_split(layout, epilogue, M, N, K);
     if (ns > 1) return (size_t)ns * M * N * sizeof(float);
   }
@@ -699,6 +714,17 @@ extern "C" int crl_gemm_bf16(int layout, int epilogue, int64_t M, int64_t N, int
     return launch_rest();
   }
   if (g_policy == 0 && bk == 64) {
+    const int nh = half_chip_split(layout, epilogue, M, N, K);
+    if (nh > 1 && ws && ws_bytes >= (size_t)nh * M * N * sizeof(float)) {
+      GemmArgs sl = a;
+      sl.bias = nullptr; sl.aux = nullptr; sl.resid = nullptr;
+      sl.C = ws; sl.ldc = (int)N; sl.slab_stride = (size_t)M * N;
+      sl.ntm = (int)((M + 255) / 256); sl.ntn = (int)((N + 255) / 256);
+      sl.kchunk = (int)((K / 64 + nh - 1) / nh);
+      const int nsl = (int)((K / 64 + sl.kchunk - 1) / sl.kchunk);
+      if (int rc = big_launch(layout, CRL_EPI_F32, sl, nsl, s)) return rc;
+      return reduce_slabs(a, nsl, "crl_gemm_bf16(half-chip split reduce)");
+    }
     const int ns = few_tiles_split(layout, epilogue, M, N, K);
     if (ns > 1 && ws && ws_bytes >= (size_t)ns * M * N * sizeof(float)) {
       GemmArgs sl = a;

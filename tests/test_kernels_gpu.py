@@ -962,6 +962,48 @@ def test_gemm_quarter_full_chip_long_contraction_split(dev):
     assert torch.equal(o32, o32b), 'slab reduction must be deterministic'
 
 
+def test_gemm_half_chip_long_contraction_split(dev):
+    """round 6: forward / dgrad GEMMs whose 256x256 tiles fill at most half the chip behind a contraction of >= 64 K tiles (the decoder's 8184-row
+    fc2 / fc1 dgrad: 128 tiles x 64 K tiles; the LM-head dgrad: 128 tiles x 786) run as contraction slices of the 4-wave 256x256 kernel + the slab
+    reduce that applies the epilogue, not as 512 small tiles: workspace, values against fp32, determinism, and the reservation of CUs switches it off"""
+    from pixparse_amd import hip, ops
+    M, N = 8184, 1024
+    for K, tol in ((4096, 3e-2), (50304, 1e-1)):
+        assert hip.query('crl_gemm_ws_bytes', hip.NN, ops.EPI_BF16, M, N, K) == 2 * M * N * 4
+        dy = rnd((M, K), dev, 1.0, 7, BF16)
+        w = rnd((K, N), dev, 0.02, 8, BF16)
+        rows = torch.cat([torch.randperm(M, generator=torch.Generator().manual_seed(2))[:126], torch.tensor([0, M - 1])]).to(dev)
+        ref = dy[rows].float() @ w.float()
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_dgrad(dy, w, out)
+        close(out[rows], ref, 1e-2, tol, f'half-chip split NN bf16 K={K}')
+        out2 = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.linear_dgrad(dy, w, out2)
+        assert torch.equal(out, out2), 'slab reduction must be deterministic'
+        hip.call('crl_gemm_set_policy', 1)                   # the 128x128 kernel: same values up to the summation order
+        try:
+            ops.linear_dgrad(dy, w, out2)
+        finally:
+            hip.call('crl_gemm_set_policy', 0)
+        close(out[rows], out2[rows].float(), 1e-2, tol, 'against the small-tile kernel')
+    # forward layout with bias + fp32 residual (fc2 of a decoder layer)
+    K = 4096
+    x = rnd((M, K), dev, 1.0, 1, BF16)
+    wt = rnd((N, K), dev, 0.02, 2, BF16)
+    bias = rnd((N,), dev, 0.5, 3)
+    resid = rnd((M, N), dev, 1.0, 4)
+    assert hip.query('crl_gemm_ws_bytes', hip.NT, ops.EPI_F32_RESID, M, N, K) == 2 * M * N * 4
+    want = resid + (x.float() @ wt.float().t() + bias.to(BF16).float()).to(BF16).float()
+    y = resid.clone()
+    ops.linear_fwd(x, wt, bias, y, ops.EPI_F32_RESID, resid=y)
+    close(y, want, 1e-2, 3e-2, 'half-chip split NT resid')
+    ops.gemm_set_reserved_cus(16)                            # 240 CUs: 128 tiles are more than half -> one launch of small tiles again
+    try:
+        assert hip.query('crl_gemm_ws_bytes', hip.NT, ops.EPI_F32_RESID, M, N, K) == 0
+    finally:
+        ops.gemm_set_reserved_cus(0)
+
+
 @pytest.mark.parametrize('Mrows,N,K', [(5000, 1024, 1024), (49512 // 4, 1024, 512), (6000, 520, 448), (300, 264, 192), (4000, 2048, 256), (70000, 256, 256)])
 def test_wgrad_with_bias_gradient(dev, Mrows, N, K):
     """linear_wgrad(..., dbias=...): the bias gradient (column sums of dy) from the weight-gradient call.  The 4-wave kernel sums the columns of its A
