@@ -1004,7 +1004,8 @@ def test_gemm_half_chip_long_contraction_split(dev):
         ops.gemm_set_reserved_cus(0)
 
 
-@pytest.mark.parametrize('Mrows,N,K', [(5000, 1024, 1024), (49512 // 4, 1024, 512), (6000, 520, 448), (300, 264, 192), (4000, 2048, 256), (70000, 256, 256)])
+@pytest.mark.parametrize('Mrows,N,K', [(5000, 1024, 1024), (49512 // 4, 1024, 512), (6000, 520, 448), (300, 264, 192), (4000, 2048, 256), (70000, 256, 256),
+                                       (2048, 4352, 5120), (8000, 512, 768)])      # the last two: a persistent launch (340 tiles, no contraction split), three column tiles (two share the duty)
 def test_wgrad_with_bias_gradient(dev, Mrows, N, K):
     """linear_wgrad(..., dbias=...): the bias gradient (column sums of dy) from the weight-gradient call.  The 4-wave kernel sums the columns of its A
     operand on the matrix pipe (eight MFMAs against a fragment of ones on the K tiles a wave is on duty for; the two waves and the <= 4 column
