@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of compile-time knobs of ONE csrc file on the kernel micro-benchmarks:
-#   ab_kernels.sh gemm2x.hip gemm2x "pol=3" "-DG2X_STAGGER=0" "-DG2X_STAGGER=1"
+#   ab_kernels.sh gemm4w.hip gemm4w "" "-DG4_CU_STAGGER=0" "-DG4_CU_STAGGER=1"
 # (file, scripts/bench_kernels.py mode, grep pattern, flag sets...)
 cd "$(dirname "$0")/.."
 source scripts/_ab_common.sh
