@@ -33,7 +33,8 @@ descriptors' num_records are zeroed in the stream: s_live counts the tiles left 
 The statement is entered with K tiles 0 and 1 of the output tile staged by the C++ wrapper (it issues them under the previous tile's epilogue)
 and left with every accumulator complete, no memory operation outstanding and every wave behind a barrier (the LDS is free).
 Diagnostics: G4W_DROP=class,... (timing-only builds, WRONG results: dsread dma barrier vmwait), G4W_OPTS=alpha=0 (no ALPHA barrier: the B pieces
-follow BETA), scripts/ab_g4w.sh builds such variants into separate libraries.
+follow BETA), G4W_OPTS=nostage0 (overlapped form, timing only: no staging of K tiles 0 and 1 at the entry -- the ceiling of a cross-tile prefetch,
+profiles/r6_gemm_tile_boundary_pricing.txt); scripts/ab_g4w.sh builds such variants into separate libraries.
 """
 import os
 import sys
@@ -352,10 +353,12 @@ def generate(layout, ovl=None, cs=False):
                 E(I(f's_cselect_b32 s{SRD[opnd] + 2}, s{SRD[opnd] + 2}, 0', 'salu'))
                 for piece in G.dma_group(opnd, tile, tile):
                     for ins in piece:
+                        if OPTS.get('nostage0') and ins.kind == 'dma':       # timing-only (wrong results): what would a tile boundary cost if K tiles 0 and 1 were already there?
+                            continue
                         E(ins)
                 E(I(f's_add_u32 {op(f"s_off{opnd}")}, {op(f"s_off{opnd}")}, {op(f"s_kt{opnd}")}', 'salu'))
             E(I(f's_sub_u32 {op("s_live")}, {op("s_live")}, 1', 'salu'))
-        H.out.append(I('s_waitcnt vmcnt(32)', 'wait'))        # the 8 bias loads (oldest) have landed, the 32 staging pieces stay in flight
+        H.out.append(I('s_waitcnt vmcnt(0)' if OPTS.get('nostage0') else 's_waitcnt vmcnt(32)', 'wait'))        # the 8 bias loads (oldest) have landed, the 32 staging pieces stay in flight
         for ins in G.readout_math():
             E(ins)
     # ---- K tiles 0 and 1 have landed for every wave -> barrier -> fragments of (tile 0, k-step 0)
