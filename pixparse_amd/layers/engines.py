@@ -91,11 +91,21 @@ class _Base:
                           dx_colsum=self.G(bias_of + '.bias') if bias_of else None)
 
     # Linear backward: wgrad + bias grad (dgrad is issued by the caller: its epilogue differs)
+    # round 6: on the FIRST micro-step of an accumulation window (every step at grad_accum_steps = 1) the weight-gradient GEMMs and the bias
+    # gradients that ride them OVERWRITE the gradient arena instead of adding to the zeros AdamW left there: the split-K reduce / the fp32
+    # epilogue skip the read of 2.1 GB of old values per step (same bits: 0 + s == s).  Set by CrullerModel.backward(first_micro=...); every
+    # other producer (LayerNorm, embeddings, position tables: sparse or small) keeps accumulating into the zero-filled arena.
+    first_micro = False
+
+    @property
+    def acc(self) -> bool:
+        return not self.first_micro
+
     def lin_wgrad(self, name, dy, x, has_bias=True, n=None, k=None):
         gw = self.G(name + '.weight')
         gw2 = gw.view(gw.shape[0], -1)
         # the bias gradient (column sums of dy) rides the weight-gradient GEMM, which streams dy anyway
-        ops.linear_wgrad(dy, x, gw2, True, n=n, k=k, dbias=self.G(name + '.bias') if has_bias else None)
+        ops.linear_wgrad(dy, x, gw2, self.acc, n=n, k=k, dbias=self.G(name + '.bias') if has_bias else None, dbias_accumulate=self.acc)
 
 
 # ============================================================================================ ViT
@@ -746,7 +756,7 @@ class BartEngine(_Base):
         Eg = self.arena.grad(self.prefix + dp + 'embed_tokens.weight', padded=True).view(self.Vp, D)
         dyb = self.buf('dyb', (M, D), BF16)        # bf16 gradient arriving at a layer output from GEMM consumers
         ops.linear_dgrad(dlogits, Ew, dyb)
-        ops.linear_wgrad(dlogits, self.h_last16, Eg, True)
+        ops.linear_wgrad(dlogits, self.h_last16, Eg, self.acc)       # (tied weight: the embedding backward below ADDS its rows to this)
         dy32 = None                                 # fp32 gradient arriving through the residual path
         dt = self.buf('dt', (M, D), F32)
         dtb = self.buf('dtb', (M, D), BF16)
@@ -791,7 +801,7 @@ class BartEngine(_Base):
             # d(encoder output) accumulates over the layers: the first one written (the last layer) overwrites, so denc needs no zero fill
             if not fused_kv:
                 ops.linear_dgrad(dkv2, self.fw('w', lp, 'encoder_attn', 'k_proj', 2), denc, EPI_F32 if i == self.L - 1 else EPI_F32_ACC)
-            ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), True, dbias=self.fb('g', lp, 'encoder_attn', 'k_proj', 2))
+            ops.linear_wgrad(dkv2, enc16, self.fw('g', lp, 'encoder_attn', 'k_proj', 2), self.acc, dbias=self.fb('g', lp, 'encoder_attn', 'k_proj', 2), dbias_accumulate=self.acc)
             # ---- h1 = LN1(t1), t1 = h_in + out_s(causal_attn(qkv(h_in_b)))
             self._branch_bwd(lp + 'self_attn_layer_norm', k + '.ln1', g('.t1'), dt2, dhb, dt, dtb, lp + 'self_attn.out_proj', 1 + 3 * i)
             ops.linear_dgrad(dtb, self.W(lp + 'self_attn.out_proj.weight'), do)
@@ -800,7 +810,7 @@ class BartEngine(_Base):
             ops.attn_bwd(q3[:, :, 0:D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], g('.o1').view(B, T, D), do.view(B, T, D), g('.lse1'), delta,
                          dq3[:, :, 0:D], dq3[:, :, D:2 * D], dq3[:, :, 2 * D:], H, scale, True, drop=drop, site=200 + 2 * i, q_prescaled=True)
             ops.linear_dgrad(dqkv, self.fw('w', lp, 'self_attn', 'q_proj', 3), dyb)
-            ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), True, dbias=self.fb('g', lp, 'self_attn', 'q_proj', 3))
+            ops.linear_wgrad(dqkv, g('.hb'), self.fw('g', lp, 'self_attn', 'q_proj', 3), self.acc, dbias=self.fb('g', lp, 'self_attn', 'q_proj', 3), dbias_accumulate=self.acc)
             dy32 = dt  # residual-path gradient for the layer below (dt now holds d t1)
             if on_layer_done:
                 on_layer_done(self.prefix + lp + 'self_attn.q_proj.weight')

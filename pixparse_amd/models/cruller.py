@@ -23,6 +23,10 @@ ENC_PREFIX = 'image_encoder.trunk.'
 DEC_PREFIX = 'text_decoder.trunk.'
 
 
+
+import os as _os
+_WGRAD_OVERWRITE = _os.environ.get('PIXPARSE_AMD_WGRAD_OVERWRITE', '1') != '0'      # A/B switch (INTEGRATION.md knob table)
+
 class _Container(nn.Module):
     """bare module used to reproduce the reference's state_dict key hierarchy"""
 
@@ -427,10 +431,13 @@ class Cruller(nn.Module):
         ops.cross_entropy(logits, self._target, self.vocab_size, loss_mul, grad_mul, self._loss, n_valid, row_loss, logits, grad_mul_dev)
         return self._loss
 
-    def backward(self, on_ready: Optional[Callable[[str], None]] = None):
+    def backward(self, on_ready: Optional[Callable[[str], None]] = None, first_micro: bool = False):
         """backward of the last forward_loss(); weight gradients accumulate into arena.g.  ``on_ready(name)`` is
-        called as the sweep passes arena entry ``name``: every gradient at or after it (layout order) is final."""
+        called as the sweep passes arena entry ``name``: every gradient at or after it (layout order) is final.
+        first_micro: the gradient arena holds zeros (the first micro-step behind an optimiser step that zero-filled it): the weight-gradient
+        GEMMs then overwrite instead of adding to those zeros (layers/engines.py _Base.first_micro; same bits, 2.1 GB less traffic at cfg-3)."""
         enc, dec, bufs = self._ensure_engines()
+        enc.first_micro = dec.first_micro = bool(first_micro) and _WGRAD_OVERWRITE
         assert self.arena.g is not None, 'call alloc_training_state() (train_setup) before backward'
         S = enc.out_tokens()
         denc = bufs.get('denc', (dec.B * S, dec.D), torch.float32)     # written (not accumulated) by the decoder's last layer first

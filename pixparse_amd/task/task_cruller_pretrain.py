@@ -183,10 +183,10 @@ class TaskCrullerPretrain(TaskTrain):
         return self.model.forward_loss(image_input, text_input, text_target, loss_mul=1.0 / accum, grad_mul=1.0 / accum,
                                        grad_mul_dev=self.scaler.scale_tensor())
 
-    def _backward(self, need_update: bool):
+    def _backward(self, need_update: bool, first_micro: bool = False):
         self.reducer.enabled = need_update or not self.has_no_sync
         self.reducer.begin()
-        self.model.backward(self.reducer.on_ready if self.reducer.active else None)
+        self.model.backward(self.reducer.on_ready if self.reducer.active else None, first_micro=first_micro)
         self.reducer.finish()
         if need_update:
             opt = self.cfg.opt
@@ -195,7 +195,7 @@ class TaskCrullerPretrain(TaskTrain):
                                 grad_divisor=self.reducer.grad_divisor())
             self.model.refresh_shadows(full=False)
 
-    def _graphed_micro_step(self, image_input, text_input, text_target, need_update: bool):
+    def _graphed_micro_step(self, image_input, text_input, text_target, need_update: bool, first_micro: bool = False):
         """forward + CE + backward (+ optimiser tail on update steps) replayed from a hipGraph.  The batch is copied into static device
         buffers; the first micro-step of each kind (with / without the optimiser tail) runs eagerly (it sizes every activation buffer
         and scratch), the second is captured and replayed, all later ones are replays.  Same kernels, same arguments, same order as the
@@ -208,16 +208,17 @@ class TaskCrullerPretrain(TaskTrain):
         gi, gt, gy = self._graph_in
         if shapes != (tuple(gi.shape), tuple(gt.shape), tuple(gy.shape)):      # a ragged last batch: run it eagerly
             loss = self.forward(image_input, text_input, text_target)
-            self._backward(need_update)
+            self._backward(need_update, first_micro)
             return loss
         gi.copy_(image_input, non_blocking=True)
         gt.copy_(text_input, non_blocking=True)
         gy.copy_(text_target, non_blocking=True)
-        st = self._graphs.get(need_update)
+        kind = (need_update, first_micro)       # the captured kernels differ: optimiser tail, overwrite / accumulate weight gradients
+        st = self._graphs.get(kind)
         if st is None:
             loss = self.forward(gi, gt, gy)
-            self._backward(need_update)
-            self._graphs[need_update] = 'warm'
+            self._backward(need_update, first_micro)
+            self._graphs[kind] = 'warm'
             return loss
         if st == 'warm':
             torch.cuda.synchronize()
@@ -226,8 +227,8 @@ class TaskCrullerPretrain(TaskTrain):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self.forward(gi, gt, gy)
-                self._backward(need_update)
-            self._graphs[need_update] = st = graph
+                self._backward(need_update, first_micro)
+            self._graphs[kind] = st = graph
         st.replay()
         return self.model._loss
 
@@ -247,11 +248,13 @@ class TaskCrullerPretrain(TaskTrain):
 
         accum_steps = self.cfg.opt.grad_accum_steps
         need_update = (self.interval_batch_idx + 1) % accum_steps == 0
+        # the first micro-step behind a zero-filled gradient arena (train_interval_start / the AdamW kernel's fused zero fill)
+        first_micro = self.interval_batch_idx % accum_steps == 0
         if getattr(self, '_graph_on', False):
-            loss = self._graphed_micro_step(image_input, text_input, text_target, need_update)
+            loss = self._graphed_micro_step(image_input, text_input, text_target, need_update, first_micro)
         else:
             loss = self.forward(image_input, text_input, text_target)
-            self._backward(need_update)
+            self._backward(need_update, first_micro)
         self.last_loss = loss
 
         self.batch_idx += 1

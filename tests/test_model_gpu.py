@@ -619,7 +619,8 @@ def test_graphed_train_step_equals_eager(dev, accum):
         return rec, ar.p.clone(), ar.m.clone(), ar.v.clone(), kinds
     eager, pe, me, ve, _ = run(False)
     graph, pg, mg, vg, kinds = run(True)
-    assert kinds == ({True: 'CUDAGraph'} if accum == 1 else {True: 'CUDAGraph', False: 'CUDAGraph'})
+    # graphs are keyed by (optimiser tail, first micro-step of the accumulation window: its weight gradients overwrite the arena)
+    assert kinds == ({(True, True): 'CUDAGraph'} if accum == 1 else {(False, True): 'CUDAGraph', (True, False): 'CUDAGraph'})
     assert eager == graph, list(zip(eager, graph))
     assert torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg)
     # the device-side LR is the scheduler's closed form: host mirror (set AFTER the update, for the next one) vs the device word of the update
@@ -629,6 +630,53 @@ def test_graphed_train_step_equals_eager(dev, accum):
     w, t = 4 // accum, 8 // accum          # one warm-up interval, two intervals in all, 4 // accum updates per interval
     want = [1e-3 * u / w if u < w else 0.5 * 1e-3 * (1 + math.cos(math.pi * u / t)) if u < t else 0.0 for u in range(n_upd)]
     assert all(abs(a - b) <= 1e-9 + 1e-6 * b for a, b in zip(lrs, want)), (lrs, want)
+
+
+@pytest.mark.parametrize('enc', ['vit_test', 'swin_test'])
+@pytest.mark.parametrize('accum', [1, 3])
+def test_weight_gradients_overwrite_on_first_micro_step_same_bits(dev, monkeypatch, enc, accum):
+    """round 6: on the first micro-step of an accumulation window the weight-gradient GEMMs (and the bias gradients that ride them) overwrite the
+    zero-filled gradient arena instead of adding to it (CrullerModel.backward(first_micro=True); PIXPARSE_AMD_WGRAD_OVERWRITE=0 switches it off).
+    Same bits: 7 micro-steps with clip-norm at accumulation 1 and 3 (an update mid-interval, a window cut by the interval end), tied embedding
+    (LM-head gradient overwrites, the embedding rows are added behind it), ViT and Swin encoders: identical losses, gradient norms, parameters, moments"""
+    from pixparse_amd.data import synthetic_batch
+    from pixparse_amd.framework import DeviceEnv, OptimizationCfg
+    from pixparse_amd.models import cruller as cruller_mod
+    from pixparse_amd.task import TaskCrullerPretrain, TaskCrullerPretrainCfg
+    _register_test_archs()
+    L, layers = 24, 2
+    img = (37, 50) if enc == 'vit_test' else (64, 64)
+
+    def run(overwrite):
+        monkeypatch.setattr(cruller_mod, '_WGRAD_OVERWRITE', overwrite)
+        cfg = TaskCrullerPretrainCfg(num_intervals=2, num_warmup_intervals=1, eval_frequency=1000, dtype='bfloat16', graph_step=False,
+                                     opt=OptimizationCfg(learning_rate=1e-3, betas=(0.9, 0.98), clip_grad_value=1.0, clip_grad_mode='norm',
+                                                         grad_accum_steps=accum),
+                                     model=_cfg(enc, img, 'RGB', layers, L))
+        torch.manual_seed(3)
+        task = TaskCrullerPretrain(cfg, DeviceEnv())
+        task.train_setup(num_batches_per_interval=4)
+        rec, seen = [], []
+        for i in range(7):
+            if i % 4 == 0:
+                task.train_interval_start()
+            task.train_step(synthetic_batch(2, 3, img, L, task.vocab_size, seed=60 + i, ragged=True))
+            st = task.optimizer.state.cpu()
+            rec.append((float(task.last_loss), float(st[0]), float(st[3])))
+            seen.append(task.model._engines[0].first_micro)
+        ar = task.model.arena
+        return rec, ar.p.clone(), ar.m.clone(), ar.v.clone(), ar.g.clone(), seen
+    off, po, mo, vo, go, seen_off = run(False)
+    on, pn, mn, vn, gn, seen_on = run(True)
+    assert not any(seen_off)
+    assert seen_on == [(i % 4) % accum == 0 for i in range(7)], seen_on
+    if enc == 'vit_test':
+        assert off == on, list(zip(off, on))
+        assert torch.equal(po, pn) and torch.equal(mo, mn) and torch.equal(vo, vn) and torch.equal(go, gn)
+    else:       # Swin: the relative-position-bias gradients are summed with float atomics (1e-10 run to run, whatever the switch says)
+        assert all(abs(a[0] - b[0]) <= 1e-5 and abs(a[1] - b[1]) <= 1e-5 * max(1.0, abs(a[1])) for a, b in zip(off, on)), list(zip(off, on))
+        for x, y in ((po, pn), (mo, mn), (vo, vn), (go, gn)):
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
 
 
 def test_greedy_generation_with_prompt_prefill_vs_oracle(dev):
